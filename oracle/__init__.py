@@ -1,0 +1,22 @@
+"""TEST INFRASTRUCTURE ONLY -- the CPU oracle for the BEV-fusion detector hot path.
+
+A plain PyTorch-CPU fp32 restatement of the reference's forward / target / loss /
+decode algorithms (meg89/bevfusion_multimodal_3d_object_detection, src/*.py), each
+function citing the reference file:line it follows.  Only `tests/`,
+`__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this
+package; nothing under `bevfusion_multimodal_3d_object_detection_amd/` does.
+
+Pinning status
+--------------
+* Everything except the ResNet-18 trunk is pinned against outputs of the reference
+  itself, imported in the build container from /root/reference/src by
+  `tests/golden/make_golden.py` (fixtures under tests/golden/*.npz).
+* The ResNet-18 trunk lives in torchvision, which the reference imports
+  (src/encoders.py:11, call site :98) but neither vendors nor pins, and which is
+  absent from this image: **parity of the trunk is unpinned by the reference**.
+  `oracle/resnet18.py` restates torchvision's published ResNet-18 (BasicBlock
+  [2,2,2,2]); the fixture maker registers that restatement under the name
+  `torchvision.models` so that the reference's own encoders.py / fusion.py run on
+  top of it.  The trunk is anchored by the reference's published parameter counts
+  (demo.ipynb:419,519) and output shapes (demo.ipynb cell 6).
+"""
