@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- BEV frames/sec of the detector forward on MI355X (BASELINE.json's metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--config 2|3|1]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one forward of `FlexibleMultiModal3DDetector` over a batch of B synthetic frames
+(config 2 of BASELINE.json by default: 6 x 900x1600 cameras + 35k-point LiDAR, 128x128 BEV,
+fp32, random-init weights), inputs resident in HBM, head tensors as outputs.  Frames shard
+over ranks as independent replicas (inference has no collective) -> weak scaling.
+Rank 0 prints ONE JSON line with the whole-job frames/s, the live roofline of the dominant
+kernel (conv_igemm_f32, HIP events on the launch stream inside the timed region) and the CPU
+baseline (the oracle on the host cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from bevfusion_multimodal_3d_object_detection_amd import engine, fusion, synth   # noqa: E402
+
+CONFIGS = {
+    # BASELINE.json configs[0..2]; (modality, cams, H, W, points, radars, bev)
+    1: dict(name="camera_only 6x448x800, BEV 128x128 (reference-runnable sanity shape)",
+            modality="camera_only", cams=6, h=448, w=800, points=0, radars=0, bev=128),
+    2: dict(name="camera+LiDAR, 6x900x1600 images + 35k-point sweep, BEV 128x128",
+            modality="camera+lidar", cams=6, h=900, w=1600, points=35000, radars=0, bev=128),
+    3: dict(name="camera+LiDAR+radar, 6x900x1600 + 35k points + 5x125 radar, BEV 128x128",
+            modality="camera+lidar+radar", cams=6, h=900, w=1600, points=35000, radars=5, bev=128),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+
+
+def build_model(cfg, seed=0):
+    model = fusion.create_detector(cfg["modality"], "bev", "centernet", bev_h=cfg["bev"], bev_w=cfg["bev"])
+    synth.fill_state_dict_(model, seed)
+    return model.eval()
+
+
+def make_inputs(cfg, batch, seed, dev):
+    imgs, pts, radars = synth.frame_inputs(batch, cfg["cams"], cfg["h"], cfg["w"], cfg["points"], 4,
+                                           cfg["radars"], 125, 7, seed=seed)
+    return (imgs.to(dev) if imgs is not None else None, pts.to(dev) if pts is not None else None,
+            [r.to(dev) for r in radars] if radars else None)
+
+
+def cpu_baseline(cfg, state_dict, budget_s=12.0):
+    """The oracle (CPU restatement, oracle/ref_model.py) on the host cores, B=1, same synthetic frame."""
+    from oracle import ref_model
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ora = ref_model.make_detector(cfg["modality"], cfg["bev"], cfg["bev"])
+    ora.load_state_dict(state_dict)
+    ora.eval()
+    imgs, pts, radars = synth.frame_inputs(1, cfg["cams"], cfg["h"], cfg["w"], cfg["points"], 4,
+                                           cfg["radars"], 125, 7, seed=0x5EED + 2000)
+    with torch.no_grad():
+        ora(imgs, pts, radars or None)                      # warm-up frame
+        n, t0 = 0, time.perf_counter()
+        while n < 2 or (time.perf_counter() - t0 < budget_s and n < 8):
+            ora(imgs, pts, radars or None)
+            n += 1
+        dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit="frames/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n} frames at B=1 after 1 warm-up, oracle/ref_model.py (PyTorch-CPU fp32), same config")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="frames per step per GPU")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true", help="skip the per-launch HIP-event brackets")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    cfg = CONFIGS[args.config]
+
+    model_cpu = build_model(cfg)
+    state = {k: v.clone() for k, v in model_cpu.state_dict().items()}
+    model = model_cpu.to(dev)
+    inputs = make_inputs(cfg, args.batch, 0x5EED + 1000 * args.config + rank, dev)
+
+    def step():
+        return model(*inputs)
+
+    for _ in range(max(args.warmup, 1)):
+        out = step()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(v).all() for v in out.values()), "non-finite head output"
+
+    timer = None if args.no_kernel_timer else engine.KernelTimer()
+    engine.set_timer(timer)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    engine.set_timer(None)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        frames = world * args.batch * args.steps
+        line = {
+            "metric": "BEV frames/sec (6-cam+LiDAR, 128x128 BEV)", "value": frames / elapsed, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+            "config": {"workload": cfg["name"], "batch_per_gpu": args.batch, "parallelism": f"replicas x{world}",
+                       "weights": "random-init (synthetic, seeded)", "mode": "inference forward -> 5 head tensors"},
+        }
+        if timer is not None:
+            tot = timer.totals()
+            conv = tot.get("conv_igemm_f32")
+            if conv:
+                ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
+                line["roofline"] = {"kernel": "conv_igemm_f32", "bound": "mfma", "achieved": ach,
+                                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                                    "traffic": None, "launches_per_step": conv["launches"] / args.steps,
+                                    "avg_launch_ms": conv["ms"] / conv["launches"],
+                                    "gflop_per_step": conv["flops"] / args.steps / 1e9,
+                                    "share_of_step": conv["ms"] / (1e3 * elapsed)}
+            pool = tot.get("bev_pool")
+            if pool:
+                gbs = pool["bytes"] / (pool["ms"] * 1e-3) / 1e9
+                line["roofline_bev_pool"] = {"kernel": "cam_mean+bilinear_nhwc", "bound": "hbm", "achieved": gbs,
+                                             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                                             "traffic": None, "mb_per_step": pool["bytes"] / args.steps / 1e6}
+            stem = tot.get("stem_conv7x7_f32")
+            if stem:
+                line["stem_tflops"] = stem["flops"] / (stem["ms"] * 1e-3) / 1e12
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, state)
+            line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,257 @@
+"""ctypes binding of libbevf_hip.so (include/bevf.h).  Fails loudly if the library is missing.
+
+Every wrapper takes torch CUDA tensors, checks device / dtype / contiguity on the host,
+passes raw `data_ptr()`s and launches on torch's current HIP stream, so the launches are
+ordered with (and graph-capturable alongside) everything else torch does on that stream.
+There is no CPU fallback: a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbevf_hip.so")
+
+
+class BevfError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
+                ("res", C.c_void_p), ("y", C.c_void_p), ("colmax", C.c_void_p)] + \
+               [(n, C.c_int32) for n in ("N", "H", "W", "Cin", "x_cs", "Ho", "Wo", "Cout", "y_cs", "res_cs",
+                                         "KH", "KW", "stride", "pad", "relu", "rows_per_group", "tile")]
+
+
+class RadarDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p * 4), ("scale", C.c_void_p * 4), ("shift", C.c_void_p * 4),
+                ("out", C.c_void_p), ("R", C.c_int32), ("B", C.c_int32), ("P", C.c_int32), ("Cin", C.c_int32),
+                ("c", C.c_int32 * 4)]
+
+
+class HeadDesc(C.Structure):
+    _fields_ = [("hid", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p * 5),
+                ("B", C.c_int32), ("P", C.c_int32), ("hc", C.c_int32), ("c", C.c_int32 * 5),
+                ("n_sigmoid", C.c_int32)]
+
+
+class DecodeDesc(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("heat", "offset", "size", "rot", "vel", "boxes", "scores", "labels",
+                                          "velocities", "count", "work")] + \
+               [(n, C.c_int32) for n in ("B", "C", "H", "W", "K", "true_labels")] + \
+               [(n, C.c_float) for n in ("thresh", "voxel", "x_min", "y_min")]
+
+
+_lib: Optional[C.CDLL] = None
+
+# name -> (restype, argtypes); the not-gpu test checks every one is exported by the .so
+SIGNATURES = {
+    "bevf_version": (C.c_int, []),
+    "bevf_last_error": (C.c_char_p, []),
+    "bevf_conv2d_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "bevf_stem_conv7x7_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p]),
+    "bevf_maxpool3x3s2_nhwc_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
+    "bevf_pointwise_smallk_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
+    "bevf_group_max_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 3 + [C.c_void_p]),
+    "bevf_radar_mlp_max_f32": (C.c_int, [C.POINTER(RadarDesc), C.c_void_p]),
+    "bevf_linear_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p]),
+    "bevf_cam_mean_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
+    "bevf_bilinear_nhwc_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 8 + [C.c_void_p]),
+    "bevf_broadcast_nhwc_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
+    "bevf_head_tail_f32": (C.c_int, [C.POINTER(HeadDesc), C.c_void_p]),
+    "bevf_nchw_to_nhwc_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
+    "bevf_nhwc_to_nchw_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
+    "bevf_fill_f32": (C.c_int, [C.c_void_p, C.c_float, C.c_size_t, C.c_void_p]),
+    "bevf_centernet_decode_work_bytes": (C.c_size_t, [C.c_int] * 5),
+    "bevf_centernet_decode_f32": (C.c_int, [C.POINTER(DecodeDesc), C.c_void_p]),
+}
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BevfError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                            f"or `make -C {os.path.dirname(LIB_PATH)}` -- there is no CPU fallback")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise BevfError(f"{what} failed ({rc}): {lib().bevf_last_error().decode()}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor], dtype=torch.float32) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise BevfError("HIP path needs CUDA/HIP tensors; got a CPU tensor (no CPU fallback in this package)")
+    if t.dtype != dtype:
+        raise BevfError(f"expected {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def _pc(t: Optional[torch.Tensor], dtype=torch.float32) -> Optional[int]:
+    if t is not None and not t.is_contiguous():
+        raise BevfError("tensor must be contiguous")
+    return _p(t, dtype)
+
+
+# ---- wrappers -------------------------------------------------------------------------------------
+
+def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, scale, shift, y: Optional[torch.Tensor], *, N: int, H: int,
+                W: int, Cin: int, x_cs: int, Cout: int, y_cs: int, KH: int, KW: int, stride: int, pad: int,
+                relu: bool, res: Optional[torch.Tensor] = None, res_cs: int = 0,
+                colmax: Optional[torch.Tensor] = None, rows_per_group: int = 0, tile: int = 0) -> None:
+    Ho = (H + 2 * pad - KH) // stride + 1
+    Wo = (W + 2 * pad - KW) // stride + 1
+    M = N * Ho * Wo
+    if x.numel() < (N * H * W - 1) * x_cs + Cin:
+        raise BevfError("conv: input buffer smaller than N*H*W*x_cs")
+    if w.numel() != Cout * KH * KW * Cin:
+        raise BevfError(f"conv: packed weight has {w.numel()} elements, expected {Cout * KH * KW * Cin}")
+    if y is not None and y.numel() < (M - 1) * y_cs + Cout:
+        raise BevfError("conv: output buffer too small")
+    if res is not None and res.numel() < (M - 1) * res_cs + Cout:
+        raise BevfError("conv: residual buffer too small")
+    for v in (scale, shift):
+        if v is not None and v.numel() != Cout:
+            raise BevfError("conv: scale/shift length != Cout")
+    if colmax is not None and colmax.numel() < -(-M // rows_per_group) * Cout:
+        raise BevfError("conv: colmax buffer too small")
+    d = ConvDesc(_p(x), _pc(w), _pc(scale), _pc(shift), _p(res), _p(y), _pc(colmax, torch.int32),
+                 N, H, W, Cin, x_cs, Ho, Wo, Cout, y_cs, res_cs, KH, KW, stride, pad, int(relu), rows_per_group, tile)
+    _check(lib().bevf_conv2d_nhwc_f32(C.byref(d), _stream()), "bevf_conv2d_nhwc_f32")
+
+
+def stem_conv7x7(x: torch.Tensor, w_packed: torch.Tensor, scale, shift, y: torch.Tensor, N: int, H: int, W: int):
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if x.numel() != N * 3 * H * W or w_packed.numel() != 148 * 64 or y.numel() < N * Ho * Wo * 64:
+        raise BevfError("stem: buffer sizes do not match N,H,W")
+    _check(lib().bevf_stem_conv7x7_f32(_pc(x), _pc(w_packed), _pc(scale), _pc(shift), _p(y), N, H, W, _stream()),
+           "bevf_stem_conv7x7_f32")
+
+
+def maxpool3x3s2(x: torch.Tensor, y: torch.Tensor, N: int, H: int, W: int, Cc: int):
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if x.numel() < N * H * W * Cc or y.numel() < N * Ho * Wo * Cc:
+        raise BevfError("maxpool: buffer too small")
+    _check(lib().bevf_maxpool3x3s2_nhwc_f32(_p(x), _p(y), N, H, W, Cc, _stream()), "bevf_maxpool3x3s2_nhwc_f32")
+
+
+def pointwise_smallk(x, w, scale, shift, y, M: int, K: int, Cout: int, relu: bool):
+    if x.numel() < M * K or w.numel() != Cout * K or y.numel() < M * Cout:
+        raise BevfError("pointwise: buffer sizes do not match M,K,Cout")
+    _check(lib().bevf_pointwise_smallk_f32(_pc(x), _pc(w), _pc(scale), _pc(shift), _p(y), M, K, Cout, int(relu),
+                                           _stream()), "bevf_pointwise_smallk_f32")
+
+
+def group_max(x, y, G: int, P: int, Cc: int):
+    if x.numel() < G * P * Cc or y.numel() < G * Cc:
+        raise BevfError("group_max: buffer too small")
+    _check(lib().bevf_group_max_f32(_p(x), _p(y), G, P, Cc, _stream()), "bevf_group_max_f32")
+
+
+def radar_mlp_max(x, ws: Sequence[torch.Tensor], scales, shifts, out, R: int, B: int, P: int, Cin: int,
+                  widths: Sequence[int]):
+    if x.numel() != R * B * P * Cin or out.numel() < B * R * widths[3]:
+        raise BevfError("radar: buffer sizes do not match R,B,P,Cin")
+    cin = Cin
+    for i in range(4):
+        if ws[i].numel() != cin * widths[i] or scales[i].numel() != widths[i] or shifts[i].numel() != widths[i]:
+            raise BevfError(f"radar: layer {i} parameter sizes wrong")
+        cin = widths[i]
+    d = RadarDesc()
+    d.x, d.out, d.R, d.B, d.P, d.Cin = _pc(x), _p(out), R, B, P, Cin
+    for i in range(4):
+        d.w[i], d.scale[i], d.shift[i], d.c[i] = _pc(ws[i]), _pc(scales[i]), _pc(shifts[i]), widths[i]
+    _check(lib().bevf_radar_mlp_max_f32(C.byref(d), _stream()), "bevf_radar_mlp_max_f32")
+
+
+def linear(x, w, bias, y, B: int, K: int, O: int, relu: bool, perm_inner: int = 0, perm_outer: int = 0):
+    if x.numel() < B * K or w.numel() != O * K or y.numel() < B * O or (bias is not None and bias.numel() != O):
+        raise BevfError("linear: buffer sizes do not match B,K,O")
+    _check(lib().bevf_linear_f32(_p(x), _pc(w), _pc(bias), _p(y), B, K, O, int(relu), perm_inner, perm_outer,
+                                 _stream()), "bevf_linear_f32")
+
+
+def cam_mean(x, y, B: int, ncam: int, P: int, Cc: int):
+    if x.numel() < B * ncam * P * Cc or y.numel() < B * P * Cc:
+        raise BevfError("cam_mean: buffer too small")
+    _check(lib().bevf_cam_mean_f32(_p(x), _p(y), B, ncam, P, Cc, _stream()), "bevf_cam_mean_f32")
+
+
+def bilinear_nhwc(x, y, B: int, Hi: int, Wi: int, Cc: int, x_cs: int, Ho: int, Wo: int, y_cs: int):
+    if x.numel() < (B * Hi * Wi - 1) * x_cs + Cc or y.numel() < (B * Ho * Wo - 1) * y_cs + Cc:
+        raise BevfError("bilinear: buffer too small")
+    _check(lib().bevf_bilinear_nhwc_f32(_p(x), _p(y), B, Hi, Wi, Cc, x_cs, Ho, Wo, y_cs, _stream()),
+           "bevf_bilinear_nhwc_f32")
+
+
+def broadcast_nhwc(v, y, B: int, P: int, Cc: int, y_cs: int):
+    if v.numel() < B * Cc or y.numel() < (B * P - 1) * y_cs + Cc:
+        raise BevfError("broadcast: buffer too small")
+    _check(lib().bevf_broadcast_nhwc_f32(_p(v), _p(y), B, P, Cc, y_cs, _stream()), "bevf_broadcast_nhwc_f32")
+
+
+def head_tail(hid, w, bias, outs: Sequence[torch.Tensor], B: int, P: int, hc: int, cs: Sequence[int], n_sigmoid: int):
+    if hid.numel() < B * P * 5 * hc or w.numel() != sum(cs) * hc or bias.numel() != sum(cs):
+        raise BevfError("head_tail: buffer sizes wrong")
+    d = HeadDesc()
+    d.hid, d.w, d.bias, d.B, d.P, d.hc, d.n_sigmoid = _p(hid), _pc(w), _pc(bias), B, P, hc, n_sigmoid
+    for k in range(5):
+        if outs[k].numel() != B * cs[k] * P:
+            raise BevfError("head_tail: output size wrong")
+        d.out[k], d.c[k] = _pc(outs[k]), cs[k]
+    _check(lib().bevf_head_tail_f32(C.byref(d), _stream()), "bevf_head_tail_f32")
+
+
+def nchw_to_nhwc(x, y, N: int, Cc: int, P: int, y_cs: int):
+    if x.numel() < N * Cc * P or y.numel() < (N * P - 1) * y_cs + Cc:
+        raise BevfError("nchw_to_nhwc: buffer too small")
+    _check(lib().bevf_nchw_to_nhwc_f32(_pc(x), _p(y), N, Cc, P, y_cs, _stream()), "bevf_nchw_to_nhwc_f32")
+
+
+def nhwc_to_nchw(x, y, N: int, Cc: int, P: int, x_cs: int):
+    if x.numel() < (N * P - 1) * x_cs + Cc or y.numel() < N * Cc * P:
+        raise BevfError("nhwc_to_nchw: buffer too small")
+    _check(lib().bevf_nhwc_to_nchw_f32(_p(x), _pc(y), N, Cc, P, x_cs, _stream()), "bevf_nhwc_to_nchw_f32")
+
+
+def fill(y: torch.Tensor, v: float):
+    _check(lib().bevf_fill_f32(_p(y), float(v), y.numel(), _stream()), "bevf_fill_f32")
+
+
+def centernet_decode(pred: dict, K: int, thresh: float, voxel: float, x_min: float, y_min: float,
+                     true_labels: bool = False):
+    heat = pred["heatmap"]
+    B, Cn, H, W = heat.shape
+    dev = heat.device
+    for k, c in (("offset", 2), ("size", 3), ("rot", 2), ("vel", 2)):
+        if tuple(pred[k].shape) != (B, c, H, W):
+            raise BevfError(f"decode: {k} has shape {tuple(pred[k].shape)}, expected {(B, c, H, W)}")
+    boxes = torch.empty(B, K, 7, device=dev)
+    scores = torch.empty(B, K, device=dev)
+    labels = torch.empty(B, K, dtype=torch.int64, device=dev)
+    vels = torch.empty(B, K, 2, device=dev)
+    count = torch.empty(B, dtype=torch.int32, device=dev)
+    work = torch.empty(lib().bevf_centernet_decode_work_bytes(B, Cn, H, W, K), dtype=torch.uint8, device=dev)
+    d = DecodeDesc(_pc(heat), _pc(pred["offset"]), _pc(pred["size"]), _pc(pred["rot"]), _pc(pred["vel"]),
+                   _p(boxes), _p(scores), _p(labels, torch.int64), _p(vels), _p(count, torch.int32),
+                   _p(work, torch.uint8), B, Cn, H, W, K, int(true_labels), thresh, voxel, x_min, y_min)
+    _check(lib().bevf_centernet_decode_f32(C.byref(d), _stream()), "bevf_centernet_decode_f32")
+    return boxes, scores, labels, vels, count

@@ -1,0 +1,14 @@
+// Library-level entry points of libbevf_hip.so: version and per-thread error text.
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void bevf_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int bevf_version(void) { return 100; }  // 0.1.0
+extern "C" const char* bevf_last_error(void) { return g_err; }

@@ -1,0 +1,233 @@
+// HBM-bound glue of the BEV path: camera mean ("BEV pooling" part 1), bilinear resample
+// (part 2, also nn.Upsample), radar broadcast, CenterNet head tail, layout changes, fill.
+// All streaming kernels move 16 B per lane, channel-contiguous (NHWC).
+#include "common.h"
+
+namespace {
+
+constexpr unsigned MAX_GRID = 256 * 8 * 4;
+
+static inline unsigned stream_grid(long long work_items) {
+  long long g = (work_items + 255) / 256;
+  return (unsigned)(g > MAX_GRID ? MAX_GRID : (g < 1 ? 1 : g));
+}
+
+// y[b][p][c] = (x[b][0][p][c] + ... + x[b][n-1][p][c]) / n      ref src/fusion.py:233-234
+__global__ __launch_bounds__(256) void cam_mean(const f32x4* __restrict__ x, f32x4* __restrict__ y, int ncam,
+                                                 long long pc4, long long total) {
+  const float div = (float)ncam;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long b = i / pc4, r = i - b * pc4;
+    const f32x4* src = x + b * ncam * pc4 + r;
+    f32x4 s = src[0];
+    for (int n = 1; n < ncam; ++n) {
+      const f32x4 v = src[(long long)n * pc4];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    s.x /= div; s.y /= div; s.z /= div; s.w /= div;
+    y[i] = s;
+  }
+}
+
+// torch upsample_bilinear2d, align_corners=False: src = scale*(dst+0.5)-0.5 clamped at 0,
+// i0 = floor, i1 = i0 + (i0 < in-1), lambda = src - i0.     ref src/fusion.py:242-247, :156
+__device__ __forceinline__ void lin_coord(int o, float scale, int in, int& i0, int& i1, float& l0, float& l1) {
+  float s = scale * ((float)o + 0.5f) - 0.5f;
+  if (s < 0.f) s = 0.f;
+  i0 = (int)s;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = fminf(fmaxf(s - (float)i0, 0.f), 1.f);
+  l0 = 1.f - l1;
+}
+
+__global__ __launch_bounds__(256) void bilinear_nhwc(const float* __restrict__ x, float* __restrict__ y, int Hi,
+                                                      int Wi, int C, int x_cs, int Ho, int Wo, int y_cs,
+                                                      float sh, float sw, long long total) {
+  const int c4 = C >> 2;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % c4) * 4;
+    long long pix = i / c4;
+    const int ow = (int)(pix % Wo);
+    const long long t = pix / Wo;
+    const int oh = (int)(t % Ho), b = (int)(t / Ho);
+    int h0, h1, w0, w1;
+    float lh0, lh1, lw0, lw1;
+    lin_coord(oh, sh, Hi, h0, h1, lh0, lh1);
+    lin_coord(ow, sw, Wi, w0, w1, lw0, lw1);
+    const float* base = x + (size_t)b * Hi * Wi * x_cs + c;
+    const f32x4 p00 = *reinterpret_cast<const f32x4*>(base + ((size_t)h0 * Wi + w0) * x_cs);
+    const f32x4 p01 = *reinterpret_cast<const f32x4*>(base + ((size_t)h0 * Wi + w1) * x_cs);
+    const f32x4 p10 = *reinterpret_cast<const f32x4*>(base + ((size_t)h1 * Wi + w0) * x_cs);
+    const f32x4 p11 = *reinterpret_cast<const f32x4*>(base + ((size_t)h1 * Wi + w1) * x_cs);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      o[j] = lh0 * (lw0 * p00[j] + lw1 * p01[j]) + lh1 * (lw0 * p10[j] + lw1 * p11[j]);
+    *reinterpret_cast<f32x4*>(y + (size_t)pix * y_cs + c) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void broadcast_nhwc(const float* __restrict__ v, float* __restrict__ y, int P,
+                                                       int C, int y_cs, long long total) {
+  const int c4 = C >> 2;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % c4) * 4;
+    const long long pix = i / c4;
+    const int b = (int)(pix / P);
+    *reinterpret_cast<f32x4*>(y + (size_t)pix * y_cs + c) = *reinterpret_cast<const f32x4*>(v + (size_t)b * C + c);
+  }
+}
+
+// CenterNet head tail (ref src/fusion.py:869-884): per pixel, five 1x1 convs on the five
+// hc-wide slices of the hidden map, sigmoid on the first n_sigmoid outputs, NCHW stores.
+struct HeadArgs {
+  const float* hid;
+  const float* w;
+  const float* bias;
+  float* out[5];
+  int B, P, hc;
+  int c[5];
+  int n_sigmoid;
+};
+
+__global__ __launch_bounds__(256) void head_tail(const HeadArgs a) {
+  extern __shared__ float wl[];   // [ctot][hc] then bias[ctot]
+  const int ctot = a.c[0] + a.c[1] + a.c[2] + a.c[3] + a.c[4];
+  for (int i = threadIdx.x; i < ctot * a.hc; i += 256) wl[i] = a.w[i];
+  for (int i = threadIdx.x; i < ctot; i += 256) wl[ctot * a.hc + i] = a.bias[i];
+  __syncthreads();
+  const float* bl = wl + ctot * a.hc;
+  const long long total = (long long)a.B * a.P;
+  for (long long pix = blockIdx.x * 256ll + threadIdx.x; pix < total; pix += (long long)gridDim.x * 256) {
+    const int b = (int)(pix / a.P), p = (int)(pix - (long long)b * a.P);
+    const float* hp = a.hid + (size_t)pix * 5 * a.hc;
+    int oc = 0;
+    for (int k = 0; k < 5; ++k) {
+      for (int c = 0; c < a.c[k]; ++c, ++oc) {
+        float acc = 0.f;
+        for (int j = 0; j < a.hc; j += 4) {
+          const f32x4 hv = *reinterpret_cast<const f32x4*>(hp + k * a.hc + j);
+          const float* wr = wl + oc * a.hc + j;
+          acc = fmaf(hv.x, wr[0], acc); acc = fmaf(hv.y, wr[1], acc);
+          acc = fmaf(hv.z, wr[2], acc); acc = fmaf(hv.w, wr[3], acc);
+        }
+        float v = acc + bl[oc];
+        if (oc < a.n_sigmoid) v = 1.f / (1.f + expf(-v));
+        a.out[k][((size_t)b * a.c[k] + c) * a.P + p] = v;
+      }
+    }
+  }
+}
+
+// [N][C][P] -> [N][P][y_cs] and back, 32x32 tiles through LDS (both sides coalesced)
+__global__ __launch_bounds__(256) void nchw_to_nhwc(const float* __restrict__ x, float* __restrict__ y, int C, int P,
+                                                     int y_cs) {
+  __shared__ float t[32][33];
+  const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, p = p0 + tx;
+    t[r][tx] = (c < C && p < P) ? x[((size_t)n * C + c) * P + p] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int p = p0 + r, c = c0 + tx;
+    if (p < P && c < C) y[((size_t)n * P + p) * y_cs + c] = t[tx][r];
+  }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw(const float* __restrict__ x, float* __restrict__ y, int C, int P,
+                                                     int x_cs) {
+  __shared__ float t[32][33];
+  const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int p = p0 + r, c = c0 + tx;
+    t[r][tx] = (c < C && p < P) ? x[((size_t)n * P + p) * x_cs + c] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, p = p0 + tx;
+    if (p < P && c < C) y[((size_t)n * C + c) * P + p] = t[tx][r];
+  }
+}
+
+__global__ __launch_bounds__(256) void fill_f32(float* __restrict__ y, float v, size_t n) {
+  for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = v;
+}
+
+}  // namespace
+
+extern "C" int bevf_cam_mean_f32(const float* x, float* y, int B, int ncam, int P, int C, void* stream) {
+  BEVF_REQUIRE(x && y, "cam_mean: null pointer");
+  BEVF_REQUIRE(B > 0 && ncam > 0 && P > 0 && C > 0 && C % 4 == 0, "cam_mean: C=%d must be a positive multiple of 4", C);
+  BEVF_REQUIRE(bevf_aligned16(x) && bevf_aligned16(y), "cam_mean: unaligned");
+  const long long pc4 = (long long)P * C / 4, total = pc4 * B;
+  hipLaunchKernelGGL(cam_mean, dim3(stream_grid(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(y), ncam, pc4, total);
+  return bevf_check_launch("bevf_cam_mean_f32");
+}
+
+extern "C" int bevf_bilinear_nhwc_f32(const float* x, float* y, int B, int Hi, int Wi, int C, int x_cs, int Ho,
+                                      int Wo, int y_cs, void* stream) {
+  BEVF_REQUIRE(x && y, "bilinear: null pointer");
+  BEVF_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0, "bilinear: bad shape (C=%d)", C);
+  BEVF_REQUIRE(x_cs >= C && y_cs >= C && x_cs % 4 == 0 && y_cs % 4 == 0, "bilinear: channel strides must be >= C and %%4");
+  BEVF_REQUIRE(bevf_aligned16(x) && bevf_aligned16(y), "bilinear: unaligned");
+  const long long total = (long long)B * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(bilinear_nhwc, dim3(stream_grid(total)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, Hi,
+                     Wi, C, x_cs, Ho, Wo, y_cs, (float)Hi / (float)Ho, (float)Wi / (float)Wo, total);
+  return bevf_check_launch("bevf_bilinear_nhwc_f32");
+}
+
+extern "C" int bevf_broadcast_nhwc_f32(const float* v, float* y, int B, int P, int C, int y_cs, void* stream) {
+  BEVF_REQUIRE(v && y, "broadcast: null pointer");
+  BEVF_REQUIRE(B > 0 && P > 0 && C > 0 && C % 4 == 0 && y_cs >= C && y_cs % 4 == 0, "broadcast: bad shape");
+  BEVF_REQUIRE(bevf_aligned16(v) && bevf_aligned16(y), "broadcast: unaligned");
+  const long long total = (long long)B * P * (C / 4);
+  hipLaunchKernelGGL(broadcast_nhwc, dim3(stream_grid(total)), dim3(256), 0, static_cast<hipStream_t>(stream), v, y, P,
+                     C, y_cs, total);
+  return bevf_check_launch("bevf_broadcast_nhwc_f32");
+}
+
+extern "C" int bevf_head_tail_f32(const bevf_head_desc* d, void* stream) {
+  BEVF_REQUIRE(d && d->hid && d->w && d->bias, "head_tail: null pointer");
+  BEVF_REQUIRE(d->B > 0 && d->P > 0 && d->hc > 0 && d->hc % 4 == 0, "head_tail: hc=%d must be a positive multiple of 4", d->hc);
+  BEVF_REQUIRE(bevf_aligned16(d->hid), "head_tail: hid unaligned");
+  HeadArgs a;
+  a.hid = d->hid; a.w = d->w; a.bias = d->bias; a.B = d->B; a.P = d->P; a.hc = d->hc; a.n_sigmoid = d->n_sigmoid;
+  int ctot = 0;
+  for (int k = 0; k < 5; ++k) {
+    BEVF_REQUIRE(d->c[k] >= 0 && (d->c[k] == 0 || d->out[k]), "head_tail: branch %d has no output buffer", k);
+    a.out[k] = d->out[k]; a.c[k] = d->c[k]; ctot += d->c[k];
+  }
+  const size_t lds = (size_t)ctot * (d->hc + 1) * sizeof(float);
+  BEVF_REQUIRE(lds <= 64 * 1024, "head_tail: weights need %zu B of LDS", lds);
+  hipLaunchKernelGGL(head_tail, dim3(stream_grid((long long)d->B * d->P)), dim3(256), lds,
+                     static_cast<hipStream_t>(stream), a);
+  return bevf_check_launch("bevf_head_tail_f32");
+}
+
+extern "C" int bevf_nchw_to_nhwc_f32(const float* x, float* y, int N, int C, int P, int y_cs, void* stream) {
+  BEVF_REQUIRE(x && y && N > 0 && C > 0 && P > 0 && y_cs >= C, "nchw_to_nhwc: bad arguments");
+  BEVF_REQUIRE(N <= 65535 && (C + 31) / 32 <= 65535, "nchw_to_nhwc: grid too large");
+  hipLaunchKernelGGL(nchw_to_nhwc, dim3((P + 31) / 32, (C + 31) / 32, N), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, y, C, P, y_cs);
+  return bevf_check_launch("bevf_nchw_to_nhwc_f32");
+}
+
+extern "C" int bevf_nhwc_to_nchw_f32(const float* x, float* y, int N, int C, int P, int x_cs, void* stream) {
+  BEVF_REQUIRE(x && y && N > 0 && C > 0 && P > 0 && x_cs >= C, "nhwc_to_nchw: bad arguments");
+  BEVF_REQUIRE(N <= 65535 && (C + 31) / 32 <= 65535, "nhwc_to_nchw: grid too large");
+  hipLaunchKernelGGL(nhwc_to_nchw, dim3((P + 31) / 32, (C + 31) / 32, N), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, y, C, P, x_cs);
+  return bevf_check_launch("bevf_nhwc_to_nchw_f32");
+}
+
+extern "C" int bevf_fill_f32(float* y, float v, size_t n, void* stream) {
+  BEVF_REQUIRE(y || n == 0, "fill: null pointer");
+  if (n == 0) return BEVF_OK;
+  hipLaunchKernelGGL(fill_f32, dim3(stream_grid((long long)n)), dim3(256), 0, static_cast<hipStream_t>(stream), y, v, n);
+  return bevf_check_launch("bevf_fill_f32");
+}

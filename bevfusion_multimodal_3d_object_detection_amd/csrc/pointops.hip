@@ -1,0 +1,231 @@
+// Point-cloud side kernels: PointNet first layer (K = 4|5), fused radar MLP + max, and the
+// weight-streaming dense layers (lidar_init, radar_proj, fusion_fc).
+#include "common.h"
+
+namespace {
+
+// ---- y[m][n] = act((sum_k x[m][k] w[n][k]) * scale[n] + shift[n]),  K <= 16 -------------------
+// PointNet conv1 + bn1 + relu (ref src/encoders.py:289).  Thread = (row, 4 channels).
+__global__ __launch_bounds__(256) void pointwise_smallk(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, float* __restrict__ y,
+                                                         int M, int K, int Cout, int relu) {
+  extern __shared__ float wl[];  // [Cout][K]
+  for (int i = threadIdx.x; i < Cout * K; i += 256) wl[i] = w[i];
+  __syncthreads();
+  const int c4 = Cout >> 2;
+  const long long total = (long long)M * c4;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int m = (int)(i / c4), n = (int)(i % c4) * 4;
+    float xv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) xv[k] = k < K ? x[(size_t)m * K + k] : 0.f;
+    f32x4 out;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float acc = 0.f;
+      for (int k = 0; k < K; ++k) acc = fmaf(xv[k], wl[(n + j) * K + k], acc);
+      float v = fmaf(acc, scale ? scale[n + j] : 1.f, shift ? shift[n + j] : 0.f);
+      out[j] = (relu && !(v > 0.f)) ? 0.f : v;
+    }
+    *reinterpret_cast<f32x4*>(y + (size_t)m * Cout + n) = out;
+  }
+}
+
+// ---- radar: 4 x (pointwise linear + BN + ReLU) + max over points, per (radar, batch elem) -------
+// ref src/encoders.py:549-555.  Points are processed in chunks of 32 through two LDS buffers;
+// the last layer keeps a running per-channel maximum in registers (channel = thread).
+struct RadarArgs {
+  const float* x;
+  const float* w[4];      // k-major: [c_{i-1}][c_i]
+  const float* scale[4];
+  const float* shift[4];
+  float* out;
+  int R, B, P, Cin;
+  int c[4];
+};
+constexpr int RCH = 32;   // points per chunk
+
+__global__ __launch_bounds__(256) void radar_mlp_max(const RadarArgs a) {
+  extern __shared__ float sm[];
+  const int cmax_a = a.c[0] > a.c[2] ? a.c[0] : a.c[2];
+  float* bufA = sm;                    // [RCH][max(Cin, c0, c2)]  input, layer-1 out, layer-3 out
+  float* bufB = sm + RCH * (cmax_a > a.Cin ? cmax_a : a.Cin);   // [RCH][c1]; layer-0 input lives in bufB first
+  const int r = blockIdx.x / a.B, b = blockIdx.x % a.B;
+  const float* xp = a.x + ((size_t)r * a.B + b) * a.P * a.Cin;
+  const int tid = threadIdx.x;
+  float run_max[4] = {0.f, 0.f, 0.f, 0.f};      // channels tid, tid+256, ... of the last layer (post-ReLU >= 0)
+
+  for (int p0 = 0; p0 < a.P; p0 += RCH) {
+    const int np = a.P - p0 < RCH ? a.P - p0 : RCH;
+    // stage the chunk's raw points in bufB as [pt][Cin]
+    for (int i = tid; i < np * a.Cin; i += 256) bufB[i] = xp[(size_t)p0 * a.Cin + i];
+    __syncthreads();
+    const float* in = bufB;
+    float* outb = bufA;
+    int cin = a.Cin;
+    for (int l = 0; l < 3; ++l) {
+      const int co = a.c[l];
+      for (int i = tid; i < np * co; i += 256) {
+        const int pt = i / co, ch = i - pt * co;
+        float acc = 0.f;
+        for (int k = 0; k < cin; ++k) acc = fmaf(in[pt * cin + k], a.w[l][(size_t)k * co + ch], acc);
+        const float v = fmaf(acc, a.scale[l][ch], a.shift[l][ch]);
+        outb[pt * co + ch] = v > 0.f ? v : 0.f;
+      }
+      __syncthreads();
+      in = outb;
+      outb = (outb == bufA) ? bufB : bufA;
+      cin = co;
+    }
+    // last layer: thread = channel, loop over the chunk's points, keep the maximum
+    const int co = a.c[3];
+    for (int j = 0; j < 4; ++j) {
+      const int ch = tid + 256 * j;
+      if (ch >= co) break;
+      const float sc = a.scale[3][ch], sh = a.shift[3][ch];
+      for (int pt = 0; pt < np; ++pt) {
+        float acc = 0.f;
+        for (int k = 0; k < cin; ++k) acc = fmaf(in[pt * cin + k], a.w[3][(size_t)k * co + ch], acc);
+        const float v = fmaf(acc, sc, sh);
+        run_max[j] = fmaxf(run_max[j], v);     // max(relu(v)) == max(0, v)
+      }
+    }
+    __syncthreads();
+  }
+  const int co = a.c[3];
+  for (int j = 0; j < 4; ++j) {
+    const int ch = tid + 256 * j;
+    if (ch < co) a.out[((size_t)b * a.R + r) * co + ch] = run_max[j];
+  }
+}
+
+// ---- dense layer, small batch: one wave per output row, weights streamed once -----------------
+template <int NB>
+__global__ __launch_bounds__(256) void linear_gemv(const float* __restrict__ x, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, float* __restrict__ y, int K,
+                                                    int O, int relu, int perm_inner, int perm_outer) {
+  const int lane = threadIdx.x & 63;
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  const int k4 = K >> 2;
+  for (int o = wave_global; o < O; o += nwaves) {
+    const f32x4* wr = reinterpret_cast<const f32x4*>(w + (size_t)o * K);
+    float acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = 0.f;
+    for (int i = lane; i < k4; i += 64) {
+      const f32x4 wv = wr[i];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const f32x4 xv = reinterpret_cast<const f32x4*>(x + (size_t)b * K)[i];
+        acc[b] = fmaf(wv.x, xv.x, acc[b]);
+        acc[b] = fmaf(wv.y, xv.y, acc[b]);
+        acc[b] = fmaf(wv.z, xv.z, acc[b]);
+        acc[b] = fmaf(wv.w, xv.w, acc[b]);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+      for (int s = 32; s >= 1; s >>= 1) acc[b] += __shfl_xor(acc[b], s);
+    }
+    if (lane == 0) {
+      const int oo = perm_inner > 0 ? (o % perm_inner) * perm_outer + o / perm_inner : o;
+      const float bv = bias ? bias[o] : 0.f;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const float v = acc[b] + bv;
+        y[(size_t)b * O + oo] = (relu && !(v > 0.f)) ? 0.f : v;
+      }
+    }
+  }
+}
+
+// ---- y[g][c] = max_p x[g][p][c]   (VFE "max over the points of a voxel", ref src/encoders.py:452) ----
+__global__ __launch_bounds__(256) void group_max(const float* __restrict__ x, float* __restrict__ y, int P, int C,
+                                                  long long total) {
+  const int c4 = C >> 2;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long g = i / c4;
+    const int c = (int)(i - g * c4) * 4;
+    const float* src = x + (size_t)g * P * C + c;
+    f32x4 m = *reinterpret_cast<const f32x4*>(src);
+    for (int p = 1; p < P; ++p) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)p * C);
+      m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+    }
+    *reinterpret_cast<f32x4*>(y + (size_t)g * C + c) = m;
+  }
+}
+
+}  // namespace
+
+extern "C" int bevf_group_max_f32(const float* x, float* y, int G, int P, int C, void* stream) {
+  BEVF_REQUIRE(x && y && G > 0 && P > 0 && C > 0 && C % 4 == 0, "group_max: bad arguments (C=%d)", C);
+  BEVF_REQUIRE(bevf_aligned16(x) && bevf_aligned16(y), "group_max: unaligned");
+  const long long total = (long long)G * (C / 4);
+  const unsigned grid = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(group_max, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, P, C, total);
+  return bevf_check_launch("bevf_group_max_f32");
+}
+
+extern "C" int bevf_pointwise_smallk_f32(const float* x, const float* w, const float* scale, const float* shift,
+                                         float* y, int M, int K, int Cout, int relu, void* stream) {
+  BEVF_REQUIRE(x && w && y, "pointwise: null pointer");
+  BEVF_REQUIRE(M > 0 && K > 0 && K <= 16 && Cout > 0 && Cout % 4 == 0, "pointwise: need 0<K<=16, Cout%%4==0 (K=%d Cout=%d)", K, Cout);
+  BEVF_REQUIRE(bevf_aligned16(y), "pointwise: y unaligned");
+  const long long total = (long long)M * (Cout / 4);
+  const unsigned grid = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(pointwise_smallk, dim3(grid), dim3(256), (size_t)Cout * K * sizeof(float),
+                     static_cast<hipStream_t>(stream), x, w, scale, shift, y, M, K, Cout, relu);
+  return bevf_check_launch("bevf_pointwise_smallk_f32");
+}
+
+extern "C" int bevf_radar_mlp_max_f32(const bevf_radar_desc* d, void* stream) {
+  BEVF_REQUIRE(d && d->x && d->out, "radar: null pointer");
+  BEVF_REQUIRE(d->R > 0 && d->B > 0 && d->P > 0 && d->Cin > 0, "radar: empty shape");
+  RadarArgs a;
+  a.x = d->x; a.out = d->out; a.R = d->R; a.B = d->B; a.P = d->P; a.Cin = d->Cin;
+  int cmax_a = d->Cin;
+  for (int i = 0; i < 4; ++i) {
+    BEVF_REQUIRE(d->w[i] && d->scale[i] && d->shift[i] && d->c[i] > 0, "radar: layer %d incomplete", i);
+    a.w[i] = d->w[i]; a.scale[i] = d->scale[i]; a.shift[i] = d->shift[i]; a.c[i] = d->c[i];
+  }
+  BEVF_REQUIRE(d->c[3] <= 1024, "radar: last width %d > 1024", d->c[3]);
+  if (d->c[0] > cmax_a) cmax_a = d->c[0];
+  if (d->c[2] > cmax_a) cmax_a = d->c[2];
+  const int cmax_b = d->c[1] > d->Cin ? d->c[1] : d->Cin;
+  const size_t lds = (size_t)RCH * (cmax_a + cmax_b) * sizeof(float);
+  BEVF_REQUIRE(lds <= 64 * 1024, "radar: layer widths need %zu B of LDS", lds);
+  hipLaunchKernelGGL(radar_mlp_max, dim3(d->R * d->B), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+  return bevf_check_launch("bevf_radar_mlp_max_f32");
+}
+
+extern "C" int bevf_linear_f32(const float* x, const float* w, const float* bias, float* y, int B, int K, int O,
+                               int relu, int perm_inner, int perm_outer, void* stream) {
+  BEVF_REQUIRE(x && w && y, "linear: null pointer");
+  BEVF_REQUIRE(B > 0 && K > 0 && O > 0 && K % 4 == 0, "linear: K=%d must be a positive multiple of 4", K);
+  BEVF_REQUIRE(bevf_aligned16(x) && bevf_aligned16(w), "linear: x/w unaligned");
+  BEVF_REQUIRE(perm_inner <= 0 || (long long)perm_inner * perm_outer == O, "linear: perm_inner*perm_outer != O");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned grid = (unsigned)((O + 3) / 4 > 4096 ? 4096 : (O + 3) / 4);
+  for (int b0 = 0; b0 < B;) {
+    const int rem = B - b0;
+    const float* xb = x + (size_t)b0 * K;
+    float* yb = y + (size_t)b0 * O;
+    if (rem >= 8) {
+      hipLaunchKernelGGL(linear_gemv<8>, dim3(grid), dim3(256), 0, st, xb, w, bias, yb, K, O, relu, perm_inner, perm_outer);
+      b0 += 8;
+    } else if (rem >= 4) {
+      hipLaunchKernelGGL(linear_gemv<4>, dim3(grid), dim3(256), 0, st, xb, w, bias, yb, K, O, relu, perm_inner, perm_outer);
+      b0 += 4;
+    } else if (rem >= 2) {
+      hipLaunchKernelGGL(linear_gemv<2>, dim3(grid), dim3(256), 0, st, xb, w, bias, yb, K, O, relu, perm_inner, perm_outer);
+      b0 += 2;
+    } else {
+      hipLaunchKernelGGL(linear_gemv<1>, dim3(grid), dim3(256), 0, st, xb, w, bias, yb, K, O, relu, perm_inner, perm_outer);
+      b0 += 1;
+    }
+  }
+  return bevf_check_launch("bevf_linear_f32");
+}

@@ -1,0 +1,477 @@
+"""Host-side execution engines: weight packing + kernel sequencing for the HIP path.
+
+One engine per reference module (camera encoder, point MLPs, BEV fusion, CenterNet head).
+An engine packs its module's parameters once per weight version (BatchNorm folded in fp64,
+conv weights re-laid OIHW -> OHWI, the lidar_init rows left in place and permuted on store),
+keeps grow-only device workspaces, and issues the C-ABI calls on torch's current stream.
+Internally every activation is fp32 NHWC; NCHW exists only at the reference's API surface.
+Inference (module.eval()) only: train-mode BatchNorm raises -- see DESIGN.md "out of scope".
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+
+# ---- packing ---------------------------------------------------------------------------------------
+
+def _bn_fold(bias: Optional[torch.Tensor], bn, cout: int, dev) -> Tuple[torch.Tensor, torch.Tensor]:
+    """scale/shift with  y = conv_nobias(x) * scale + shift  ==  bn(conv(x) + bias)   (eval mode)."""
+    b = torch.zeros(cout, dtype=torch.float64, device=dev) if bias is None else bias.detach().double()
+    if bn is None or isinstance(bn, nn.Identity):
+        return torch.ones(cout, device=dev), b.float().contiguous()
+    g = bn.weight.detach().double() if bn.weight is not None else torch.ones(cout, dtype=torch.float64, device=dev)
+    be = bn.bias.detach().double() if bn.bias is not None else torch.zeros(cout, dtype=torch.float64, device=dev)
+    scale = g / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+    shift = be + (b - bn.running_mean.detach().double()) * scale
+    return scale.float().contiguous(), shift.float().contiguous()
+
+
+@dataclass
+class PackedConv:
+    w: torch.Tensor          # OHWI, flat
+    scale: Optional[torch.Tensor]
+    shift: Optional[torch.Tensor]
+    cin: int
+    cout: int
+    k: int
+    stride: int
+    pad: int
+    relu: bool
+
+
+def pack_conv(conv, bn=None, relu: bool = True) -> PackedConv:
+    w = conv.weight.detach()
+    if w.dim() == 3:                                   # Conv1d k=1 == pointwise
+        w = w.unsqueeze(-1)
+    cout, cin, kh, kw = w.shape
+    assert kh == kw, "square kernels only"
+    stride = conv.stride[0] if isinstance(conv.stride, tuple) else conv.stride
+    pad = conv.padding[0] if isinstance(conv.padding, tuple) else conv.padding
+    scale, shift = _bn_fold(conv.bias, bn, cout, w.device)
+    return PackedConv(w.permute(0, 2, 3, 1).contiguous().view(-1).float(), scale, shift, cin, cout, kh, stride, pad, relu)
+
+
+def _check_eval(module: nn.Module) -> None:
+    for m in module.modules():
+        if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.training:
+            raise NotImplementedError(
+                "HIP path implements inference (eval-mode BatchNorm with running statistics); call .eval() first. "
+                "Train-mode forward/backward kernels are not built yet (DESIGN.md, 'next').")
+
+
+class _Engine:
+    """Weight-version tracking + grow-only workspaces."""
+
+    def __init__(self, module: nn.Module):
+        self.module = module
+        self._sig = None
+        self._bufs: Dict[str, torch.Tensor] = {}
+
+    def _signature(self):
+        return tuple((t.data_ptr(), t._version) for t in self.module.state_dict(keep_vars=True).values())
+
+    def ensure_packed(self) -> None:
+        sig = self._signature()
+        if sig != self._sig:
+            _check_eval(self.module)
+            with torch.no_grad():
+                self.pack()
+            self._sig = sig
+
+    def pack(self) -> None:  # pragma: no cover - abstract
+        raise NotImplementedError
+
+    @property
+    def device(self):
+        return next(self.module.parameters()).device
+
+    def buf(self, name: str, numel: int, dtype=torch.float32) -> torch.Tensor:
+        t = self._bufs.get(name)
+        if t is None or t.numel() < numel or t.dtype != dtype or t.device != self.device:
+            t = torch.empty(max(numel, 4), dtype=dtype, device=self.device)
+            self._bufs[name] = t
+        return t
+
+
+class KernelTimer:
+    """HIP-event brackets around individual launches on the current stream (bench.py's live roofline
+    measurement).  Off unless installed with set_timer(); adds two event records per bracket."""
+
+    def __init__(self):
+        self.spans = []          # (name, start, end, flops, bytes)
+
+    def bracket(self, name: str, flops: float = 0.0, nbytes: float = 0.0):
+        timer = self
+
+        class _Span:
+            def __enter__(self_):
+                self_.s = torch.cuda.Event(enable_timing=True)
+                self_.e = torch.cuda.Event(enable_timing=True)
+                self_.s.record()
+
+            def __exit__(self_, *exc):
+                self_.e.record()
+                timer.spans.append((name, self_.s, self_.e, flops, nbytes))
+        return _Span()
+
+    def totals(self) -> Dict[str, Dict[str, float]]:
+        """name -> {launches, ms, flops, bytes}; call after a device synchronize."""
+        out: Dict[str, Dict[str, float]] = {}
+        for name, s, e, fl, by in self.spans:
+            d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["flops"] += fl
+            d["bytes"] += by
+        return out
+
+
+_TIMER: Optional[KernelTimer] = None
+
+
+def set_timer(t: Optional[KernelTimer]) -> None:
+    global _TIMER
+    _TIMER = t
+
+
+class _NoSpan:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+def _span(name: str, flops: float = 0.0, nbytes: float = 0.0):
+    return _TIMER.bracket(name, flops, nbytes) if _TIMER is not None else _NoSpan()
+
+
+def _run_conv(pc: PackedConv, x, y, N, H, W, x_cs=None, y_cs=None, res=None, colmax=None, rows_per_group=0, tile=0):
+    ho, wo = (H + 2 * pc.pad - pc.k) // pc.stride + 1, (W + 2 * pc.pad - pc.k) // pc.stride + 1
+    with _span("conv_igemm_f32", flops=2.0 * N * ho * wo * pc.cout * pc.k * pc.k * pc.cin):
+        _conv_call(pc, x, y, N, H, W, x_cs, y_cs, res, colmax, rows_per_group, tile)
+    return ho, wo
+
+
+def _conv_call(pc: PackedConv, x, y, N, H, W, x_cs=None, y_cs=None, res=None, colmax=None, rows_per_group=0, tile=0):
+    L.conv2d_nhwc(x, pc.w, pc.scale, pc.shift, y, N=N, H=H, W=W, Cin=pc.cin, x_cs=x_cs or pc.cin, Cout=pc.cout,
+                  y_cs=y_cs or pc.cout, KH=pc.k, KW=pc.k, stride=pc.stride, pad=pc.pad, relu=pc.relu, res=res,
+                  res_cs=pc.cout if res is not None else 0, colmax=colmax, rows_per_group=rows_per_group, tile=tile)
+
+
+# ---- camera encoder (ref src/encoders.py:133-172) -----------------------------------------------------
+
+class CameraEncoderEngine(_Engine):
+    def pack(self) -> None:
+        m = self.module
+        w = m.conv1.weight.detach()                                     # (64,3,7,7)
+        assert tuple(w.shape) == (64, 3, 7, 7), "stem kernel supports the ResNet 7x7x3->64 stem only"
+        packed = torch.zeros(148, 64, device=w.device)
+        packed[:147] = w.reshape(64, 147).t()
+        self.stem_w = packed.contiguous().view(-1)
+        self.stem_scale, self.stem_shift = _bn_fold(None, m.bn1, 64, w.device)
+        self.blocks = []
+        for layer in (m.layer1, m.layer2, m.layer3):
+            for blk in layer:
+                down = None
+                if blk.downsample is not None:
+                    down = pack_conv(blk.downsample[0], blk.downsample[1], relu=False)
+                self.blocks.append((pack_conv(blk.conv1, blk.bn1, True), pack_conv(blk.conv2, blk.bn2, True), down))
+        self.proj = pack_conv(m.channel_proj[0], m.channel_proj[1], True)
+
+    def run(self, x: torch.Tensor) -> Tuple[torch.Tensor, int, int]:
+        """x: (N,3,H,W) contiguous NCHW -> (NHWC buffer [N*Hc*Wc*Cout], Hc, Wc)."""
+        self.ensure_packed()
+        N, _, H, W = x.shape
+        H1, W1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        H2, W2 = (H1 - 1) // 2 + 1, (W1 - 1) // 2 + 1
+        stem = self.buf("stem", N * H1 * W1 * 64)
+        with _span("stem_conv7x7_f32", flops=2.0 * N * H1 * W1 * 64 * 147):
+            L.stem_conv7x7(x, self.stem_w, self.stem_scale, self.stem_shift, stem, N, H, W)
+        cur = self.buf("act0", N * H2 * W2 * 64)
+        L.maxpool3x3s2(stem, cur, N, H1, W1, 64)
+        h, w = H2, W2
+        ping = 0                                       # activations ping-pong between act0 / act1
+        for c1, c2, down in self.blocks:
+            ho, wo = (h + 2 - 3) // c1.stride + 1, (w + 2 - 3) // c1.stride + 1
+            t = self.buf("tmp", N * ho * wo * c1.cout)
+            _run_conv(c1, cur, t, N, h, w)
+            idt = cur
+            if down is not None:
+                idt = self.buf("down", N * ho * wo * down.cout)
+                _run_conv(down, cur, idt, N, h, w)
+            ping ^= 1
+            out = self.buf(f"act{ping}", N * ho * wo * c2.cout)
+            _run_conv(c2, t, out, N, ho, wo, res=idt)
+            cur, h, w = out, ho, wo
+        feat = self.buf("feat", N * h * w * self.proj.cout)
+        _run_conv(self.proj, cur, feat, N, h, w)
+        return feat, h, w
+
+
+# ---- shared per-point MLP + max (ref src/encoders.py:271-306) -------------------------------------------
+
+class PointNetEngine(_Engine):
+    def pack(self) -> None:
+        m = self.module
+        convs = [getattr(m, f"conv{i}") for i in range(1, 6)]
+        bns = [getattr(m, f"bn{i}") for i in range(1, 6)]
+        w0 = convs[0].weight.detach()
+        self.cin = w0.shape[1]
+        self.w0 = w0.reshape(w0.shape[0], self.cin).contiguous().float()
+        self.s0, self.b0 = _bn_fold(convs[0].bias, bns[0], w0.shape[0], w0.device)
+        self.c0 = w0.shape[0]
+        self.layers = [pack_conv(c, b, True) for c, b in zip(convs[1:], bns[1:])]
+
+    def run(self, pts: torch.Tensor, keep_last: bool = False):
+        """pts: (B,N,C) contiguous -> (B, feat) global max feature [and the (B*N, feat) last activations]."""
+        self.ensure_packed()
+        B, N, Cc = pts.shape
+        M = B * N
+        a = self.buf("l0", M * self.c0)
+        L.pointwise_smallk(pts, self.w0, self.s0, self.b0, a, M, Cc, self.c0, True)
+        for i, pc in enumerate(self.layers[:-1]):
+            o = self.buf(f"l{i + 1}", M * pc.cout)
+            _run_conv(pc, a, o, M, 1, 1)
+            a = o
+        last = self.layers[-1]
+        gmax = torch.zeros(B, last.cout, dtype=torch.int32, device=pts.device)
+        y = self.buf("l_last", M * last.cout) if keep_last else None
+        _run_conv(last, a, y, M, 1, 1, colmax=gmax, rows_per_group=N)
+        return gmax.view(torch.float32), y
+
+
+class VFEEngine(_Engine):
+    """VFELayer (ref src/encoders.py:431-455): Linear + BN1d + ReLU per point, max over the points of a voxel."""
+
+    def pack(self) -> None:
+        m = self.module
+        w = m.linear.weight.detach()
+        self.cin, self.cout = w.shape[1], w.shape[0]
+        self.scale, self.shift = _bn_fold(m.linear.bias, m.bn, self.cout, w.device)
+        self.w = w.contiguous().float()
+        if self.cin > 16:
+            if self.cin % 32:
+                raise L.BevfError(f"VFELayer: in_channels={self.cin} must be <= 16 or a multiple of 32")
+            self.pc = PackedConv(self.w.view(-1), self.scale, self.shift, self.cin, self.cout, 1, 1, 0, True)
+
+    def run(self, x: torch.Tensor) -> torch.Tensor:
+        self.ensure_packed()
+        B, Nv, P, Cc = x.shape
+        G, M = B * Nv, B * Nv * P
+        if Cc <= 16:
+            t = self.buf("pts", M * self.cout)
+            L.pointwise_smallk(x, self.w, self.scale, self.shift, t, M, Cc, self.cout, True)
+            out = torch.empty(G, self.cout, device=x.device)
+            L.group_max(t, out, G, P, self.cout)
+            return out
+        gmax = torch.zeros(G, self.cout, dtype=torch.int32, device=x.device)
+        _run_conv(self.pc, x, None, M, 1, 1, colmax=gmax, rows_per_group=P)
+        return gmax.view(torch.float32)
+
+
+class RadarEngine(_Engine):
+    """MultiRadarEncoder: shared RadarEncoder per sweep + concat/max/mean (ref src/encoders.py:628-661)."""
+
+    def pack(self) -> None:
+        enc = self.module.radar_encoder
+        self.cin = enc.conv1.weight.shape[1]
+        self.ws, self.scales, self.shifts, self.widths = [], [], [], []
+        for i in range(1, 5):
+            conv, bn = getattr(enc, f"conv{i}"), getattr(enc, f"bn{i}")
+            w = conv.weight.detach()
+            self.ws.append(w.reshape(w.shape[0], w.shape[1]).t().contiguous().float())       # k-major
+            s, b = _bn_fold(conv.bias, bn, w.shape[0], w.device)
+            self.scales.append(s); self.shifts.append(b); self.widths.append(w.shape[0])
+        if self.module.fusion_method == "concat":
+            fc = self.module.fusion_fc
+            self.fc_w = fc.weight.detach().contiguous().float()
+            self.fc_b = fc.bias.detach().contiguous().float() if fc.bias is not None else None
+
+    def run(self, radar_list: Sequence[torch.Tensor]) -> torch.Tensor:
+        self.ensure_packed()
+        R = len(radar_list)
+        B = radar_list[0].shape[0]
+        feat = self.widths[3]
+        per = torch.empty(B, R, feat, device=self.device)
+        same = all(r.shape == radar_list[0].shape for r in radar_list)
+        if same:
+            x = torch.stack([r.contiguous() for r in radar_list], dim=0).contiguous()         # [R][B][P][Cin]
+            L.radar_mlp_max(x, self.ws, self.scales, self.shifts, per, R, B, x.shape[2], self.cin, self.widths)
+        else:
+            for r, pts in enumerate(radar_list):
+                one = torch.empty(B, 1, feat, device=self.device)
+                L.radar_mlp_max(pts.contiguous(), self.ws, self.scales, self.shifts, one, 1, B, pts.shape[1],
+                                self.cin, self.widths)
+                per[:, r] = one[:, 0]
+        method = self.module.fusion_method
+        if method == "concat":
+            K = R * feat
+            if K != self.fc_w.shape[1]:
+                raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({B}x{K} and "
+                                   f"{self.fc_w.shape[1]}x{self.fc_w.shape[0]})")
+            out = torch.empty(B, self.fc_w.shape[0], device=self.device)
+            L.linear(per, self.fc_w, self.fc_b, out, B, K, self.fc_w.shape[0], False)
+            return out
+        if method == "max":
+            return per.max(dim=1)[0]
+        if method == "mean":
+            return per.mean(dim=1)
+        raise ValueError(f"Unknown fusion method: {method}")
+
+
+# ---- BEV fusion (ref src/fusion.py:209-297) ----------------------------------------------------------------
+
+class FusionEngine(_Engine):
+    def pack(self) -> None:
+        m = self.module
+        if m.use_camera:
+            self.cam1 = pack_conv(m.camera_proj[0], m.camera_proj[1], True)
+            self.cam2 = pack_conv(m.camera_proj[3], m.camera_proj[4], True)
+        if m.use_lidar:
+            l0, l2 = m.lidar_init[0], m.lidar_init[2]
+            self.li0 = (l0.weight.detach().contiguous().float(), l0.bias.detach().contiguous().float())
+            self.li2 = (l2.weight.detach().contiguous().float(), l2.bias.detach().contiguous().float())
+            self.lup1 = pack_conv(m.lidar_upsample[0], m.lidar_upsample[1], True)
+            self.lup2 = pack_conv(m.lidar_upsample[4], m.lidar_upsample[5], True)
+        if m.use_radar:
+            r0 = m.radar_proj[0]
+            self.rp = (r0.weight.detach().contiguous().float(), r0.bias.detach().contiguous().float())
+            self.rr1 = pack_conv(m.radar_refine[0], m.radar_refine[1], True)
+            self.rr2 = pack_conv(m.radar_refine[3], m.radar_refine[4], True)
+        self.f1 = pack_conv(m.bev_fusion[0], m.bev_fusion[1], True)
+        self.f2 = pack_conv(m.bev_fusion[3], m.bev_fusion[4], True)
+
+    def run(self, cam: Optional[torch.Tensor], cam_geom: Optional[Tuple[int, int, int, int]],
+            lidar: Optional[torch.Tensor], radar: Optional[torch.Tensor]) -> Tuple[torch.Tensor, int]:
+        """cam: NHWC encoder features [B*ncam][Hc][Wc][C] with cam_geom = (B, ncam, Hc, Wc); lidar (B,1024);
+        radar (B,256).  Returns the fused NHWC map [B][S_h*S_w][bev_channels] and B."""
+        self.ensure_packed()
+        m = self.module
+        Sh, Sw, bc = m.bev_h, m.bev_w, m.bev_channels
+        P = Sh * Sw
+        present = []
+        if m.use_camera and cam is not None:
+            present.append("c")
+        if m.use_lidar and lidar is not None:
+            present.append("l")
+        if m.use_radar and radar is not None:
+            present.append("r")
+        if not present:
+            raise ValueError("No modality features provided")
+        B = cam_geom[0] if "c" in present else (lidar.shape[0] if "l" in present else radar.shape[0])
+        ccs = bc * len(present)
+        if ccs != self.f1.cin:
+            raise RuntimeError(f"Given groups=1, weight of size [{self.f1.cout}, {self.f1.cin}, 3, 3], expected input"
+                               f"[{B}, {ccs}, {Sh}, {Sw}] to have {self.f1.cin} channels, but got {ccs} channels instead")
+        concat = self.buf("concat", B * P * ccs)
+        slot = 0
+        if "c" in present:
+            _, ncam, Hc, Wc = cam_geom
+            Cc = self.cam1.cin
+            pooled = cam
+            if ncam > 1:
+                pooled = self.buf("cam_mean", B * Hc * Wc * Cc)
+                with _span("bev_pool", nbytes=4.0 * B * Hc * Wc * Cc * (ncam + 1)):
+                    L.cam_mean(cam, pooled, B, ncam, Hc * Wc, Cc)
+            t1 = self.buf("cam_t1", B * Hc * Wc * self.cam1.cout)
+            _run_conv(self.cam1, pooled, t1, B, Hc, Wc)
+            t2 = self.buf("cam_t2", B * Hc * Wc * self.cam2.cout)
+            _run_conv(self.cam2, t1, t2, B, Hc, Wc)
+            with _span("bev_pool", nbytes=4.0 * B * bc * (Hc * Wc + Sh * Sw)):
+                L.bilinear_nhwc(t2, concat[slot * bc:], B, Hc, Wc, bc, bc, Sh, Sw, ccs)
+            slot += 1
+        if "l" in present:
+            s0 = m.lidar_start_size
+            hid = self.buf("lid_h", B * self.li0[0].shape[0])
+            L.linear(lidar.contiguous(), self.li0[0], self.li0[1], hid, B, self.li0[0].shape[1], self.li0[0].shape[0], True)
+            O = self.li2[0].shape[0]
+            ch = O // (s0 * s0)
+            grid0 = self.buf("lid_g0", B * O)
+            L.linear(hid, self.li2[0], self.li2[1], grid0, B, self.li2[0].shape[1], O, False, s0 * s0, ch)
+            g1 = self.buf("lid_g1", B * s0 * s0 * self.lup1.cout)
+            _run_conv(self.lup1, grid0, g1, B, s0, s0)
+            s1 = 2 * s0
+            g2 = self.buf("lid_g2", B * s1 * s1 * self.lup1.cout)
+            L.bilinear_nhwc(g1, g2, B, s0, s0, self.lup1.cout, self.lup1.cout, s1, s1, self.lup1.cout)
+            if (s1, s1) == (Sh, Sw):
+                _run_conv(self.lup2, g2, concat[slot * bc:], B, s1, s1, y_cs=ccs)
+            else:
+                # extension beyond the reference (which crashes at the concat for BEV != 50x50):
+                # bilinear resize of the 50x50 LiDAR map, exactly like the camera branch
+                g3 = self.buf("lid_g3", B * s1 * s1 * bc)
+                _run_conv(self.lup2, g2, g3, B, s1, s1)
+                L.bilinear_nhwc(g3, concat[slot * bc:], B, s1, s1, bc, bc, Sh, Sw, ccs)
+            slot += 1
+        if "r" in present:
+            rv = self.buf("rad_v", B * bc)
+            L.linear(radar.contiguous(), self.rp[0], self.rp[1], rv, B, self.rp[0].shape[1], bc, True)
+            r0 = self.buf("rad_0", B * P * bc)
+            L.broadcast_nhwc(rv, r0, B, P, bc, bc)
+            r1 = self.buf("rad_1", B * P * bc)
+            _run_conv(self.rr1, r0, r1, B, Sh, Sw)
+            _run_conv(self.rr2, r1, concat[slot * bc:], B, Sh, Sw, y_cs=ccs)
+            slot += 1
+        f1 = self.buf("fus_1", B * P * self.f1.cout)
+        _run_conv(self.f1, concat, f1, B, Sh, Sw)
+        out = self.buf("fus_2", B * P * self.f2.cout)
+        _run_conv(self.f2, f1, out, B, Sh, Sw)
+        return out, B
+
+
+# ---- CenterNet head (ref src/fusion.py:869-884) --------------------------------------------------------------
+
+HEAD_BRANCHES = ("heatmap", "offset", "size", "rot", "vel")
+
+
+class HeadEngine(_Engine):
+    def pack(self) -> None:
+        m = self.module
+        convs3 = [getattr(m, f"{n}_head")[0] for n in HEAD_BRANCHES]
+        convs1 = [getattr(m, f"{n}_head")[2] for n in HEAD_BRANCHES]
+        w3 = torch.cat([c.weight.detach() for c in convs3], dim=0)                 # (5*hc, Cin, 3, 3)
+        b3 = torch.cat([c.bias.detach() for c in convs3], dim=0)
+        self.hc = convs3[0].weight.shape[0]
+        self.conv = PackedConv(w3.permute(0, 2, 3, 1).contiguous().view(-1).float(), None, b3.contiguous().float(),
+                               w3.shape[1], w3.shape[0], 3, 1, 1, True)
+        self.cs = [c.weight.shape[0] for c in convs1]
+        self.w1 = torch.cat([c.weight.detach().reshape(c.weight.shape[0], self.hc) for c in convs1], 0).contiguous().float()
+        self.b1 = torch.cat([c.bias.detach() for c in convs1], 0).contiguous().float()
+
+    def run(self, bev_nhwc: torch.Tensor, B: int, H: int, W: int) -> Dict[str, torch.Tensor]:
+        self.ensure_packed()
+        P = H * W
+        hid = self.buf("hid", B * P * self.conv.cout)
+        _run_conv(self.conv, bev_nhwc, hid, B, H, W)
+        outs = [torch.empty(B, c, H, W, device=bev_nhwc.device) for c in self.cs]
+        L.head_tail(hid, self.w1, self.b1, outs, B, P, self.hc, self.cs, self.cs[0])
+        return dict(zip(HEAD_BRANCHES, outs))
+
+
+# ---- layout helpers at the API surface ----------------------------------------------------------------------
+
+def to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """(N,C,H,W) -> flat NHWC buffer."""
+    N, Cc, H, W = x.shape
+    y = torch.empty(N * H * W * Cc, device=x.device)
+    L.nchw_to_nhwc(x.contiguous(), y, N, Cc, H * W, Cc)
+    return y
+
+
+def to_nchw(buf: torch.Tensor, N: int, Cc: int, H: int, W: int) -> torch.Tensor:
+    y = torch.empty(N, Cc, H, W, device=buf.device)
+    L.nhwc_to_nchw(buf, y, N, Cc, H * W, Cc)
+    return y
+
+
+def require_cuda(*tensors) -> None:
+    for t in tensors:
+        if t is not None and isinstance(t, torch.Tensor) and not t.is_cuda:
+            raise L.BevfError("this package runs the hot path on MI355X only: move the module and its inputs to "
+                              "'cuda' (there is no CPU fallback; the CPU oracle lives under oracle/ for tests)")

@@ -1,0 +1,173 @@
+/*
+ * bevf.h -- C-ABI of libbevf_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * BEV-fusion detector hot path of meg89/bevfusion_multimodal_3d_object_detection.
+ *
+ * The reference has no FFI of its own: its boundary is the Python module API
+ * of src/encoders.py, src/fusion.py, src/fusion_detection.py and src/centernet_target.py.  Each
+ * entry point below names the reference lines whose arithmetic it replaces; the Python host
+ * in bevfusion_multimodal_3d_object_detection_amd/ binds them with ctypes and keeps the
+ * reference's class names, constructor signatures and state-dict keys.
+ *
+ * Conventions: plain device pointers and sizes, no torch types; every call is asynchronous on
+ * `stream` (a hipStream_t passed as void*), never allocates, never synchronises, is re-entrant
+ * and graph-capturable; returns 0 or a negative bevf_status, message via bevf_last_error().
+ * Activations are fp32 NHWC ("pixel-major": [image][row][col][channel]) with an explicit
+ * per-pixel channel stride so producers write straight into channel slices of a concat buffer.
+ */
+#ifndef BEVF_H
+#define BEVF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  BEVF_OK = 0,
+  BEVF_ERR_ARG = -1,      /* shape / alignment / null-pointer contract violated */
+  BEVF_ERR_LAUNCH = -2,   /* hipLaunchKernel reported an error */
+  BEVF_ERR_UNSUPPORTED = -3
+} bevf_status;
+
+int bevf_version(void);
+const char* bevf_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Implicit-GEMM 2-D convolution on v_mfma_f32_32x32x2_f32 (exact fp32), fused epilogue
+ *     y = act( conv(x, w) * scale + shift (+ res) )
+ * Replaces every nn.Conv2d(+BatchNorm2d eval)(+ReLU)(+residual add) on the path:
+ *   ResNet-18 layer1..3 + channel_proj   ref src/encoders.py:159-165 (torchvision BasicBlock)
+ *   camera_proj / lidar_upsample / radar_refine / bev_fusion   ref src/fusion.py:126-207,239-295
+ *   CenterNet 3x3 branches (5 fused into one Cout=320 conv)    ref src/fusion.py:822-854
+ * and, with KH=KW=1, the shared per-point MLP layers (nn.Conv1d k=1 + BatchNorm1d + ReLU)
+ *   PointNetLiDAREncoder conv2..conv5   ref src/encoders.py:290-295
+ * With `colmax` set the output is not stored; instead the per-group column maximum
+ * (torch.max(x, 2)[0], ref src/encoders.py:298) is accumulated with integer atomics on the
+ * non-negative post-ReLU bit patterns (order-independent, hence deterministic).
+ * Requires Cin % 32 == 0, x_cs % 4 == 0, 16-byte aligned x / w.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* x;      /* [N][H][W][x_cs], first Cin channels of each pixel are read        */
+  const float* w;      /* [Cout][KH][KW][Cin]  (OHWI)                                        */
+  const float* scale;  /* [Cout] or NULL (1)   folded BN: gamma / sqrt(var + eps)            */
+  const float* shift;  /* [Cout] or NULL (0)   beta - mean*scale + conv_bias*scale           */
+  const float* res;    /* optional residual [N*Ho*Wo][res_cs], added before the activation   */
+  float* y;            /* [N*Ho*Wo][y_cs] (may be NULL when colmax is set)                   */
+  uint32_t* colmax;    /* optional [ceil(M/rows_per_group)][Cout], caller zeroes it          */
+  int32_t N, H, W, Cin, x_cs;
+  int32_t Ho, Wo, Cout, y_cs, res_cs;
+  int32_t KH, KW, stride, pad;
+  int32_t relu;            /* 0: none, 1: ReLU                                               */
+  int32_t rows_per_group;  /* colmax grouping (points per batch element)                     */
+  int32_t tile;            /* 0: auto; else forces a tile variant (bench/tests)              */
+} bevf_conv_desc;
+int bevf_conv2d_nhwc_f32(const bevf_conv_desc* d, void* stream);
+
+/* ResNet stem: 7x7 stride-2 pad-3 conv on a planar 3-channel image + BN + ReLU,
+ * ref src/encoders.py:154-156 (torchvision conv1/bn1/relu).  x: [N][3][H][W] (NCHW, as the
+ * reference's callers hand it over), w: the filter bank packed k-major [148][64] with
+ * k = c*49 + kh*7 + kw and a zero row k = 147 (packed once per weight update by the host),
+ * y: [N][Ho][Wo][64] NHWC.                                                                  */
+int bevf_stem_conv7x7_f32(const float* x, const float* w, const float* scale, const float* shift,
+                          float* y, int N, int H, int W, void* stream);
+
+/* 3x3 stride-2 pad-1 max-pool, NHWC, ref src/encoders.py:157.                               */
+int bevf_maxpool3x3s2_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
+
+/* Small-K pointwise layer y[m][n] = act((sum_k x[m][k] w[n][k]) * scale[n] + shift[n]), K <= 16:
+ * PointNet conv1 (K = 4|5), ref src/encoders.py:289.                                         */
+int bevf_pointwise_smallk_f32(const float* x, const float* w, const float* scale, const float* shift,
+                              float* y, int M, int K, int Cout, int relu, void* stream);
+
+/* y[g][c] = max over the P rows of group g: the per-voxel max of VFELayer ("pillar reduction"),
+ * ref src/encoders.py:451-452.  x: [G][P][C] post-ReLU point features -> y: [G][C].           */
+int bevf_group_max_f32(const float* x, float* y, int G, int P, int C, void* stream);
+
+/* One radar sweep -> 256-d feature: 4 x (Conv1d k=1 + BN + ReLU) + max over points, all in
+ * LDS, one workgroup per (radar, batch element).  ref src/encoders.py:549-555, loop :642-644.
+ * x: [R][B][P][Cin]; w_i packed k-major [c_{i-1}][c_i]; out: [B][R][c4] (== torch.stack(dim=1)). */
+typedef struct {
+  const float* x;
+  const float* w[4];
+  const float* scale[4];
+  const float* shift[4];
+  float* out;
+  int32_t R, B, P, Cin;
+  int32_t c[4];
+} bevf_radar_desc;
+int bevf_radar_mlp_max_f32(const bevf_radar_desc* d, void* stream);
+
+/* Dense layer for small batch (weight-streaming GEMV): y[b][perm(o)] = act(W[o].x[b] + bias[o]).
+ * lidar_init (ref src/fusion.py:144-148,258), radar_proj (:183-186,274), fusion_fc
+ * (ref src/encoders.py:624,653).  perm(o) = (o % perm_inner) * perm_outer + o / perm_inner when
+ * perm_inner > 0 (writes the (B,128,25,25) view of ref :259 directly as NHWC), else o.        */
+int bevf_linear_f32(const float* x, const float* w, const float* bias, float* y, int B, int K, int O,
+                    int relu, int perm_inner, int perm_outer, void* stream);
+
+/* Camera "BEV pooling" part 1: mean over the cameras, ref src/fusion.py:233-234.
+ * x: [B][ncam][P][C] -> y: [B][P][C]; sum in camera order, then true division by ncam.       */
+int bevf_cam_mean_f32(const float* x, float* y, int B, int ncam, int P, int C, void* stream);
+
+/* Camera "BEV pooling" part 2 / nn.Upsample: bilinear resample, align_corners=False,
+ * ref src/fusion.py:242-247 and :156.  NHWC in (stride x_cs) -> NHWC out slice (stride y_cs). */
+int bevf_bilinear_nhwc_f32(const float* x, float* y, int B, int Hi, int Wi, int C, int x_cs,
+                           int Ho, int Wo, int y_cs, void* stream);
+
+/* radar broadcast, ref src/fusion.py:277-278: y[b][p][0:C] = v[b][0:C] for p < P.            */
+int bevf_broadcast_nhwc_f32(const float* v, float* y, int B, int P, int C, int y_cs, void* stream);
+
+/* CenterNet head tail: block-diagonal 1x1 convs of the five branches + sigmoid on the heatmap,
+ * ref src/fusion.py:825,832,839,846,853,869-884.  hid: [B*P][5*hc] post-ReLU hidden maps;
+ * w: concatenated [sum(c_k)][hc]; bias: [sum(c_k)]; outputs NCHW (B,c_k,H,W) as the reference
+ * returns them.  n_sigmoid = number of leading output channels passed through sigmoid.       */
+typedef struct {
+  const float* hid;
+  const float* w;
+  const float* bias;
+  float* out[5];
+  int32_t B, P, hc;
+  int32_t c[5];
+  int32_t n_sigmoid;
+} bevf_head_desc;
+int bevf_head_tail_f32(const bevf_head_desc* d, void* stream);
+
+/* Layout changes at the module-API boundary (the reference's tensors are NCHW).              */
+int bevf_nchw_to_nhwc_f32(const float* x, float* y, int N, int C, int P, int y_cs, void* stream);
+int bevf_nhwc_to_nchw_f32(const float* x, float* y, int N, int C, int P, int x_cs, void* stream);
+
+/* (N,P,Cin) point rows -> NHWC rows of a padded width (zero fill), for Cin not a multiple of 4 */
+int bevf_fill_f32(float* y, float v, size_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Post-processing, ref src/centernet_target.py:326-452 / src/fusion_detection.py:695-820:
+ * 3x3 keep-mask (_nms), per-class top-K then top-K of the C*K pool (_topk), gather + box
+ * assembly.  One workgroup per batch element; outputs are fixed-size [B][K] records plus a
+ * per-frame count of entries with score > thresh (they are a prefix: scores are sorted).
+ * Ties are broken by the lower flattened index, like a stable descending sort.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* heat;   /* (B,C,H,W) post-sigmoid */
+  const float* offset; /* (B,2,H,W) */
+  const float* size;   /* (B,3,H,W) */
+  const float* rot;    /* (B,2,H,W) */
+  const float* vel;    /* (B,2,H,W) */
+  float* boxes;        /* [B][K][7]  x,y,z,w,l,h,yaw */
+  float* scores;       /* [B][K]     descending */
+  int64_t* labels;     /* [B][K]     */
+  float* velocities;   /* [B][K][2]  */
+  int32_t* count;      /* [B]        entries with score > thresh (a prefix) */
+  void* work;          /* scratch of bevf_centernet_decode_work_bytes(B,C,H,W,K) bytes */
+  int32_t B, C, H, W, K;
+  int32_t true_labels; /* 0: reference behaviour (label is always 0, ref centernet_target.py:434);
+                          1: opt-in fix, label = class of the winning heatmap plane */
+  float thresh, voxel, x_min, y_min;
+} bevf_decode_desc;
+size_t bevf_centernet_decode_work_bytes(int B, int C, int H, int W, int K);
+int bevf_centernet_decode_f32(const bevf_decode_desc* d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEVF_H */
