@@ -12,6 +12,12 @@
 // bank-conflict free.  Each lane reads 4 consecutive k of its row: lane half h of k-group g
 // owns k = 8g+4h..8g+4h+3, and MFMA step s pairs (k=8g+s | k=8g+4+s) -- a fixed permutation
 // of the K order that A and B share.
+//
+// Wave quantisation: a layer whose big-tile count is not a multiple of the 512 resident
+// workgroups (2 per CU) would pay a whole extra round for a few leftover tiles.  The hybrid
+// kernel therefore covers rows [0, m_split) with big tiles (whole rounds) and the remaining
+// rows with 64x64 tiles in the SAME grid: the small workgroups are dispatched last and fill
+// CUs as the big ones drain.
 #include "common.h"
 
 namespace {
@@ -29,26 +35,25 @@ struct ConvArgs {
   int KH, KW, stride, pad;
   int relu, rows_per_group;
   int M, K, tilesM, tilesN;
+  int m_split, nbig, tilesN_big;   // hybrid launch: blocks [0,nbig) = big tiles over rows [0,m_split)
 };
 
 constexpr int BK = 32;
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
+__device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const int m_lo, const int m_hi,
+                                          const int tm, const int tn) {
   constexpr int WAVES_N = BN / WN;
   constexpr int MI = WM / 32, NI = WN / 32;
   constexpr int AP = BM / 32, BP = BN / 32;
   static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
 
-  extern __shared__ __attribute__((aligned(16))) float lds[];
   float* As = lds;                 // [2][BM][BK]
   float* Bs = lds + 2 * BM * BK;   // [2][BN][BK]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int sid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tn = sid % p.tilesN, tm = sid / p.tilesN;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = m_lo + tm * BM, n0 = tn * BN;
 
   // ---- staging role: thread owns 16-B chunk `chunk` of rows srow + 32*j -------------------
   const int chunk = tid & 7, srow = tid >> 3;
@@ -57,7 +62,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
 #pragma unroll
   for (int j = 0; j < AP; ++j) {
     const int m = m0 + srow + 32 * j;
-    if (m < p.M) {
+    if (m < m_hi) {
       const int n = m / HoWo, r = m - n * HoWo;
       const int oh = r / p.Wo, ow = r - oh * p.Wo;
       a_pix[j] = n * p.H * p.W;
@@ -162,41 +167,90 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
   }
 
   // ---- epilogue: C[i][j], j = lane&31 (channel), i = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel) ----
+  // Branch-free per element: residual loads of a 32x32 tile are issued as one batch (rows past
+  // the end are clamped for the load and masked at the store).
   const int m_base = m0 + wm * WM, n_base = n0 + wn * WN;
   bool cm_fast = false;
   int cm_group = 0;
   if (p.colmax) {
     cm_group = m0 / p.rows_per_group;
-    cm_fast = (m0 + BM <= p.M) && ((m0 + BM - 1) / p.rows_per_group == cm_group);
+    cm_fast = (m0 + BM <= m_hi) && ((m0 + BM - 1) / p.rows_per_group == cm_group);
   }
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int n = n_base + ni * 32 + l31;
     const bool nok = n < p.Cout;
-    const float sc = (nok && p.scale) ? p.scale[n] : 1.f;
-    const float sh = (nok && p.shift) ? p.shift[n] : 0.f;
+    const int nc = nok ? n : p.Cout - 1;
+    const float sc = p.scale ? p.scale[nc] : 1.f;
+    const float sh = p.shift ? p.shift[nc] : 0.f;
     float vmax = 0.f;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
+      const int mrow = m_base + mi * 32 + 4 * h;
+      float rv[16];
+      if (p.res) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int m = mrow + (r & 3) + 8 * (r >> 2);
+          m = m < m_hi ? m : m_hi - 1;
+          rv[r] = p.res[(size_t)m * p.res_cs + nc];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+      }
+      float v[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m_base + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < p.M && nok) {
-          float v = fmaf(acc[mi][ni][r], sc, sh);
-          if (p.res) v += p.res[(size_t)m * p.res_cs + n];
-          if (p.relu) v = v > 0.f ? v : 0.f;
-          if (p.y) p.y[(size_t)m * p.y_cs + n] = v;
-          if (p.colmax) {
-            if (cm_fast) vmax = fmaxf(vmax, v);
-            else atomicMax(&p.colmax[(size_t)(m / p.rows_per_group) * p.Cout + n], __float_as_uint(v > 0.f ? v : 0.f));
+        const float t = fmaf(acc[mi][ni][r], sc, sh) + rv[r];
+        v[r] = p.relu ? fmaxf(t, 0.f) : t;
+      }
+      if (p.y) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mrow + (r & 3) + 8 * (r >> 2);
+          if (m < m_hi && nok) p.y[(size_t)m * p.y_cs + n] = v[r];
+        }
+      }
+      if (p.colmax) {
+        if (cm_fast) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) vmax = fmaxf(vmax, v[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = mrow + (r & 3) + 8 * (r >> 2);
+            if (m < m_hi && nok)
+              atomicMax(&p.colmax[(size_t)(m / p.rows_per_group) * p.Cout + n], __float_as_uint(fmaxf(v[r], 0.f)));
           }
         }
       }
     }
     if (p.colmax && cm_fast) {
       vmax = fmaxf(vmax, __shfl_xor(vmax, 32));
-      if (h == 0 && nok) atomicMax(&p.colmax[(size_t)cm_group * p.Cout + n], __float_as_uint(vmax > 0.f ? vmax : 0.f));
+      if (h == 0 && nok) atomicMax(&p.colmax[(size_t)cm_group * p.Cout + n], __float_as_uint(fmaxf(vmax, 0.f)));
     }
+  }
+}
+
+// single tile shape over all rows
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int sid = xcd_remap(blockIdx.x, gridDim.x);
+  conv_tile<BM, BN, WM, WN>(p, lds, 0, p.M, sid / p.tilesN, sid % p.tilesN);
+}
+
+// big tiles over rows [0, m_split) + 64x64 tiles over rows [m_split, M) in one grid
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_f32_hybrid(const ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  if ((int)blockIdx.x < p.nbig) {
+    const int sid = xcd_remap(blockIdx.x, p.nbig);
+    conv_tile<BM, BN, WM, WN>(p, lds, 0, p.m_split, sid / p.tilesN_big, sid % p.tilesN_big);
+  } else {
+    const int sid = xcd_remap(blockIdx.x - p.nbig, gridDim.x - p.nbig);
+    conv_tile<64, 64, 32, 32>(p, lds, p.m_split, p.M, sid / p.tilesN, sid % p.tilesN);
   }
 }
 
@@ -215,6 +269,40 @@ int launch(const ConvArgs& a0, hipStream_t st) {
   }
   hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN>), dim3(a.tilesM * a.tilesN), dim3(256), lds_bytes, st, a);
   return bevf_check_launch("bevf_conv2d_nhwc_f32");
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_hybrid(const ConvArgs& a0, int big_mtiles, hipStream_t st) {
+  ConvArgs a = a0;
+  a.tilesN_big = (a.Cout + BN - 1) / BN;
+  a.nbig = big_mtiles * a.tilesN_big;
+  a.m_split = big_mtiles * BM;
+  a.tilesN = (a.Cout + 63) / 64;                               // small-tile geometry
+  a.tilesM = (a.M - a.m_split + 63) / 64;
+  const int nsmall = a.tilesM * a.tilesN;
+  constexpr size_t lds_bytes = size_t(2) * (BM + BN) * BK * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (lds_bytes > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32_hybrid<BM, BN, WM, WN>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv_igemm_f32_hybrid<BM, BN, WM, WN>), dim3(a.nbig + nsmall), dim3(256), lds_bytes, st, a);
+  return bevf_check_launch("bevf_conv2d_nhwc_f32");
+}
+
+constexpr int kResidentBig = 512;     // 256 CUs x 2 workgroups (64-80 KB of LDS each)
+
+// Rows that big tiles should cover so that they fill whole rounds of the chip; the rest goes to
+// 64x64 tiles.  Returns the number of big M-tiles (0 = all small, tilesM = all big).
+static int split_big_mtiles(long long M, int BM, int tilesN_big) {
+  const int tilesM = (int)((M + BM - 1) / BM);
+  const long long nb = (long long)tilesM * tilesN_big;
+  const long long rem = nb % kResidentBig;
+  if (rem == 0 || rem >= (kResidentBig * 3) / 4) return tilesM;          // last round is (nearly) full anyway
+  const long long full = nb - rem;
+  return (int)(full / tilesN_big);                                       // whole rounds only (may be 0)
 }
 
 }  // namespace
@@ -242,20 +330,29 @@ extern "C" int bevf_conv2d_nhwc_f32(const bevf_conv_desc* d, void* stream) {
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
   a.relu = d->relu; a.rows_per_group = d->rows_per_group;
   a.M = (int)M; a.K = d->KH * d->KW * d->Cin; a.tilesM = a.tilesN = 0;
+  a.m_split = 0; a.nbig = 0; a.tilesN_big = 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
 
-  int tile = d->tile;
-  if (tile == 0) {
-    // largest tile that still gives every CU two workgroups; narrow-N layers use the tall tile
-    auto wgs = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((d->Cout + bn - 1) / bn); };
-    if (d->Cout <= 64) tile = wgs(256, 64) >= 512 ? 2 : (wgs(128, 64) >= 384 ? 3 : 4);
-    else tile = wgs(128, 128) >= 384 ? 1 : 4;
-  }
-  switch (tile) {
+  switch (d->tile) {
+    case 0: break;
     case 1: return launch<128, 128, 64, 64>(a, st);
     case 2: return launch<256, 64, 64, 64>(a, st);
     case 3: return launch<128, 64, 64, 32>(a, st);
     case 4: return launch<64, 64, 32, 32>(a, st);
-    default: bevf_set_error("conv: unknown tile variant %d", tile); return BEVF_ERR_ARG;
+    case 5: return launch_hybrid<128, 128, 64, 64>(a, (int)(M / 128) / 2, st);     // tests: forced mid split
+    case 6: return launch_hybrid<256, 64, 64, 64>(a, (int)(M / 256) / 2, st);
+    default: bevf_set_error("conv: unknown tile variant %d", d->tile); return BEVF_ERR_ARG;
   }
+  // auto: big tiles for whole rounds of the chip, 64x64 tiles for the remaining rows
+  if (d->Cout <= 64) {
+    const int big = split_big_mtiles(M, 256, 1);
+    if (big == 0) return launch<64, 64, 32, 32>(a, st);
+    if (big == (int)((M + 255) / 256)) return launch<256, 64, 64, 64>(a, st);
+    return launch_hybrid<256, 64, 64, 64>(a, big, st);
+  }
+  const int tn = (d->Cout + 127) / 128;
+  const int big = split_big_mtiles(M, 128, tn);
+  if (big == 0) return launch<64, 64, 32, 32>(a, st);
+  if (big == (int)((M + 127) / 128)) return launch<128, 128, 64, 64>(a, st);
+  return launch_hybrid<128, 128, 64, 64>(a, big, st);
 }

@@ -40,6 +40,9 @@ CONV_CASES = [
     (3, 7, 5, 256, 320, 3, 1, 1, True, False, 0),       # Cout not a multiple of the N tile (fused head conv)
     (1, 5, 5, 768, 512, 3, 1, 1, True, False, 4),       # 3-modality concat width
     (1, 1, 1, 32, 32, 1, 1, 0, True, False, 0),         # degenerate single pixel
+    (1, 30, 31, 64, 128, 3, 1, 1, True, True, 5),       # hybrid: 3 big 128x128 M-tiles + 64x64 tail, residual
+    (2, 33, 37, 64, 64, 3, 2, 1, True, True, 6),        # hybrid 256x64 + tail, stride 2
+    (1, 64, 72, 32, 320, 1, 1, 0, False, False, 5),     # hybrid, ragged N in both tile shapes
 ]
 
 
@@ -88,7 +91,9 @@ def test_conv_colmax(gpu, B, npts):
     w = synth.normal((Cout, Cin), 22, 0, 0.125)
     shift = synth.normal((Cout,), 23, 0, 0.2)
     ref = F.relu(x @ w.t() + shift).view(B, npts, Cout).max(dim=1)[0]
-    for tile in (0, 1, 4):
+    for tile in (0, 1, 4, 5):
+        if tile == 5 and B * npts < 256:
+            continue
         cm = torch.zeros(B, Cout, dtype=torch.int32, device=gpu)
         L.conv2d_nhwc(x.view(-1).cuda(), w.contiguous().view(-1).cuda(), None, shift.cuda(), None, N=B * npts, H=1,
                       W=1, Cin=Cin, x_cs=Cin, Cout=Cout, y_cs=Cout, KH=1, KW=1, stride=1, pad=0, relu=True,
