@@ -20,6 +20,8 @@
 // CUs as the big ones drain.
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 struct ConvArgs {
@@ -40,6 +42,21 @@ struct ConvArgs {
 
 constexpr int BK = 32;
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOob = 0x80000000u;   // >= num_records of every descriptor below: the load returns 0
+
+__device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+  return __builtin_bit_cast(f32x4, v);
+}
+
+// K-loop design notes (what the ISA must look like): v_mfma_f32_32x32x2_f32 runs at the fp32
+// VALU rate, so every VALU instruction in the loop costs MFMA issue time.  The loop therefore
+// has no per-step address arithmetic: global operands come through buffer loads whose per-lane
+// byte offset is fixed for the whole tile (invalid = padding taps / rows past the end use an
+// out-of-range offset, which the hardware answers with zeros), the filter tap moves the
+// descriptor's scalar base, the channel chunk is the scalar offset, LDS addresses are
+// precomputed and everything that varies per step is an instruction immediate.
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const int m_lo, const int m_hi,
                                           const int tm, const int tn) {
@@ -47,9 +64,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const i
   constexpr int MI = WM / 32, NI = WN / 32;
   constexpr int AP = BM / 32, BP = BN / 32;
   static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
-
-  float* As = lds;                 // [2][BM][BK]
-  float* Bs = lds + 2 * BM * BK;   // [2][BN][BK]
+  constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 4;   // one buffer each
+  char* const ldsb = reinterpret_cast<char*>(lds);              // [A0][A1][B0][B1]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -57,7 +73,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const i
 
   // ---- staging role: thread owns 16-B chunk `chunk` of rows srow + 32*j -------------------
   const int chunk = tid & 7, srow = tid >> 3;
-  int a_pix[AP], a_ih0[AP], a_iw0[AP];
+  unsigned a_voff[AP], a_eff[AP];
+  int a_ih0[AP], a_iw0[AP];
   const int HoWo = p.Ho * p.Wo;
 #pragma unroll
   for (int j = 0; j < AP; ++j) {
@@ -65,48 +82,73 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const i
     if (m < m_hi) {
       const int n = m / HoWo, r = m - n * HoWo;
       const int oh = r / p.Wo, ow = r - oh * p.Wo;
-      a_pix[j] = n * p.H * p.W;
+      // byte offset of the pixel under filter tap (pad,pad); the tap itself moves the scalar base
+      a_voff[j] = (unsigned)((((n * p.H + oh * p.stride) * p.W + ow * p.stride) * p.x_cs + chunk * 4) * 4);
       a_ih0[j] = oh * p.stride - p.pad;
       a_iw0[j] = ow * p.stride - p.pad;
     } else {
-      a_pix[j] = 0;
+      a_voff[j] = kOob;
       a_ih0[j] = -(1 << 24);
       a_iw0[j] = -(1 << 24);
     }
   }
-  const float* wrow[BP];
-  bool wok[BP];
+  unsigned b_voff[BP];
 #pragma unroll
   for (int j = 0; j < BP; ++j) {
     const int n = n0 + srow + 32 * j;
-    wok[j] = n < p.Cout;
-    wrow[j] = p.w + (size_t)(wok[j] ? n : 0) * p.K + chunk * 4;
+    b_voff[j] = n < p.Cout ? (unsigned)(((size_t)n * p.K + chunk * 4) * 4) : kOob;
   }
+  const __amdgpu_buffer_rsrc_t rsrcB =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)kOob, 0x00020000);
 
-  f32x4 ra[AP], rb[BP];
-  auto load_tile = [&](int kh, int kw, int c0, int kofs) {
+  int kh = 0, kw = 0, c0 = 0;                       // scalar state of the NEXT tile to load
+  auto set_tap = [&]() {                            // VALU work only when the filter tap changes
 #pragma unroll
     for (int j = 0; j < AP; ++j) {
       const int ih = a_ih0[j] + kh, iw = a_iw0[j] + kw;
-      const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-      const float* src = p.x + (size_t)(a_pix[j] + ih * p.W + iw) * p.x_cs + c0 + chunk * 4;
-      ra[j] = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+      a_eff[j] = ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? a_voff[j] : kOob;
     }
+  };
+  f32x4 ra[AP], rb[BP];
+  auto load_tile = [&](int kofs) {
+    const float* base = p.x + ((long)(kh - p.pad) * p.W + (kw - p.pad)) * p.x_cs;
+    const __amdgpu_buffer_rsrc_t rsrcA =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)kOob, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < AP; ++j) ra[j] = buf_load16(rsrcA, a_eff[j], (unsigned)c0 * 4u);
+#pragma unroll
+    for (int j = 0; j < BP; ++j) rb[j] = buf_load16(rsrcB, b_voff[j], (unsigned)kofs * 4u);
+  };
+  auto advance = [&]() {
+    c0 += BK;
+    if (c0 == p.Cin) {
+      c0 = 0;
+      if (++kw == p.KW) { kw = 0; ++kh; }
+      set_tap();
+    }
+  };
+
+  // LDS addresses (bytes).  Row r, 16-B chunk c lives at r*128 + ((c ^ ((r>>1)&7)) << 4); rows r and
+  // r+32 share the swizzle, so the j / mi / ni / buffer strides are immediates.
+  const int wr_off = srow * 128 + ((chunk ^ ((srow >> 1) & 7)) << 4);
+  const int h = lane >> 5, l31 = lane & 31;
+  int a_rd[4], b_rd[4];
+  {
+    const int ra_row = wm * WM + l31, rb_row = wn * WN + l31;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      a_rd[g] = ra_row * 128 + (((2 * g + h) ^ ((ra_row >> 1) & 7)) << 4);
+      b_rd[g] = 2 * A_BYTES + rb_row * 128 + (((2 * g + h) ^ ((rb_row >> 1) & 7)) << 4);
+    }
+  }
+  auto store_tile = [&](auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+    for (int j = 0; j < AP; ++j)
+      *reinterpret_cast<f32x4*>(ldsb + wr_off + buf * A_BYTES + j * 4096) = ra[j];
 #pragma unroll
     for (int j = 0; j < BP; ++j)
-      rb[j] = wok[j] ? *reinterpret_cast<const f32x4*>(wrow[j] + kofs) : f32x4{0.f, 0.f, 0.f, 0.f};
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < AP; ++j) {
-      const int row = srow + 32 * j;
-      *reinterpret_cast<f32x4*>(&As[(buf * BM + row) * BK + ((chunk ^ ((row >> 1) & 7)) << 2)]) = ra[j];
-    }
-#pragma unroll
-    for (int j = 0; j < BP; ++j) {
-      const int row = srow + 32 * j;
-      *reinterpret_cast<f32x4*>(&Bs[(buf * BN + row) * BK + ((chunk ^ ((row >> 1) & 7)) << 2)]) = rb[j];
-    }
+      *reinterpret_cast<f32x4*>(ldsb + wr_off + 2 * A_BYTES + buf * B_BYTES + j * 4096) = rb[j];
   };
 
   f32x16 acc[MI][NI];
@@ -117,23 +159,17 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const i
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  const int h = lane >> 5, l31 = lane & 31;
-  auto compute = [&](int buf) {
-    const float* Ab = As + buf * BM * BK;
-    const float* Bb = Bs + buf * BN * BK;
+  auto compute = [&](auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       f32x4 a[MI], b[NI];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        const int row = wm * WM + mi * 32 + l31;
-        a[mi] = *reinterpret_cast<const f32x4*>(&Ab[row * BK + (((2 * g + h) ^ ((row >> 1) & 7)) << 2)]);
-      }
+      for (int mi = 0; mi < MI; ++mi)
+        a[mi] = *reinterpret_cast<const f32x4*>(ldsb + a_rd[g] + buf * A_BYTES + mi * 4096);
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int row = wn * WN + ni * 32 + l31;
-        b[ni] = *reinterpret_cast<const f32x4*>(&Bb[row * BK + (((2 * g + h) ^ ((row >> 1) & 7)) << 2)]);
-      }
+      for (int ni = 0; ni < NI; ++ni)
+        b[ni] = *reinterpret_cast<const f32x4*>(ldsb + b_rd[g] + buf * B_BYTES + ni * 4096);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -144,25 +180,33 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const i
     }
   };
 
-  // ---- K loop --------------------------------------------------------------------------------
+  // ---- K loop: loads for step t+1 are issued before the MFMAs of step t, written to the other
+  //      LDS buffer after them; one barrier per step; unrolled by two so the buffer is static ----
   const int KT = p.K / BK;
-  int kh = 0, kw = 0, c0 = 0;
-  load_tile(0, 0, 0, 0);
-  store_tile(0);
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  set_tap();
+  load_tile(0);
+  store_tile(B0{});
   __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
-    const int cur = kt & 1;
-    const bool more = kt + 1 < KT;
+  int kt = 0;
+  for (; kt + 2 <= KT; kt += 2) {
+    advance();
+    load_tile((kt + 1) * BK);
+    compute(B0{});
+    store_tile(B1{});
+    __syncthreads();
+    const bool more = kt + 2 < KT;
     if (more) {
-      c0 += BK;
-      if (c0 == p.Cin) {
-        c0 = 0;
-        if (++kw == p.KW) { kw = 0; ++kh; }
-      }
-      load_tile(kh, kw, c0, (kt + 1) * BK);
+      advance();
+      load_tile((kt + 2) * BK);
     }
-    compute(cur);
-    if (more) store_tile(cur ^ 1);
+    compute(B1{});
+    if (more) store_tile(B0{});
+    __syncthreads();
+  }
+  if (kt < KT) {                                    // odd number of K steps: the last one sits in buffer 0
+    compute(B0{});
     __syncthreads();
   }
 
@@ -320,6 +364,9 @@ extern "C" int bevf_conv2d_nhwc_f32(const bevf_conv_desc* d, void* stream) {
   BEVF_REQUIRE(!d->y || d->y_cs >= d->Cout, "conv: y_cs=%d < Cout=%d", d->y_cs, d->Cout);
   BEVF_REQUIRE(!d->res || d->res_cs >= d->Cout, "conv: res_cs < Cout");
   BEVF_REQUIRE(!d->colmax || (d->rows_per_group > 0 && d->relu), "conv: colmax needs rows_per_group > 0 and relu");
+  BEVF_REQUIRE((long long)d->N * d->H * d->W * d->x_cs * 4 < (1ll << 31) &&
+                   (long long)d->Cout * d->KH * d->KW * d->Cin * 4 < (1ll << 31),
+               "conv: input / weight buffers must stay below 2 GiB (32-bit buffer offsets)");
   const long long M = (long long)d->N * d->Ho * d->Wo;
   BEVF_REQUIRE(M < (1ll << 31) && (long long)d->N * d->H * d->W < (1ll << 31), "conv: pixel count overflows int32");
 
@@ -349,6 +396,11 @@ extern "C" int bevf_conv2d_nhwc_f32(const bevf_conv_desc* d, void* stream) {
     if (big == 0) return launch<64, 64, 32, 32>(a, st);
     if (big == (int)((M + 255) / 256)) return launch<256, 64, 64, 64>(a, st);
     return launch_hybrid<256, 64, 64, 64>(a, big, st);
+  }
+  // a ragged last 128-wide N tile would waste MFMA work (Cout = 320: 17 %): use 64-wide tiles there
+  if (d->Cout % 128 != 0 && (d->Cout % 128) <= 64) {
+    const long long ws = ((M + 127) / 128) * ((d->Cout + 63) / 64);
+    return ws >= 384 ? launch<128, 64, 64, 32>(a, st) : launch<64, 64, 32, 32>(a, st);
   }
   const int tn = (d->Cout + 127) / 128;
   const int big = split_big_mtiles(M, 128, tn);

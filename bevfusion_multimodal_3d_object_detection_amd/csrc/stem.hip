@@ -1,82 +1,105 @@
 // ResNet stem: 7x7 stride-2 pad-3 convolution of a planar 3-channel image, fused BN + ReLU,
 // on v_mfma_f32_32x32x2_f32.  ref src/encoders.py:154-156.
 //
-// One workgroup = one output row segment of 128 pixels x all 64 channels.  The 3 x 7 input
+// One workgroup = TH = 4 output rows x 128 pixels x all 64 channels.  The 3 x (2*TH+5) input
 // rows it needs (261 columns) are staged once in LDS straight from the NCHW image (coalesced
 // along W, zero-filled outside the image); the whole filter bank sits beside it as
-// [k][channel] (packed once by the host) so the B-operand reads are conflict-free.  The A operand is read
-// element-wise out of the patch: A[pixel i][k=(c,kh,kw)] = patch[c*7+kh][2*i + kw].
-// K = 147 is padded to 148 and split in two halves of 74: lane half h walks k = p + 74*h.
+// [k][channel] (packed once by the host) so the B-operand reads are conflict-free, and is
+// amortised over the four rows.  The A operand is read element-wise out of the patch:
+// A[pixel i of row ro][k=(c,kh,kw)] = patch[c][2*ro + kh][2*i + kw].
+// K = 147 is padded to 148 and split in two halves of 74: lane half h walks k = p + 74*h
+// (the padded k = 147 has a zero filter row; its A address is clamped into the patch).
 #include "common.h"
 
 namespace {
 
-constexpr int TP = 128;              // output pixels per workgroup (along W)
+constexpr int TP = 128;              // output pixels per workgroup row (along W)
+constexpr int TH = 4;                // output rows per workgroup
 constexpr int PW = 2 * TP + 8;       // patch row pitch (261 used)
-constexpr int PROWS = 22;            // 21 patch rows + 1 zero row read by the padded k = 147
+constexpr int PR = 2 * TH + 5;       // patch rows per input channel
 constexpr int KPAD = 148, KHALF = 74;
 
 __global__ __launch_bounds__(256) void stem_conv7x7_f32(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift, float* __restrict__ y,
-                                                         int H, int W, int Ho, int Wo, int tilesW) {
-  __shared__ __attribute__((aligned(16))) float patch[PROWS * PW];
-  __shared__ __attribute__((aligned(16))) float wl[KPAD * 64];
+                                                         int H, int W, int Ho, int Wo, int tilesW, int tilesH) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* wl = smem;                      // [KPAD][64]
+  float* patch = smem + KPAD * 64;       // [3][PR][PW]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tw = blockIdx.x % tilesW;
-  const int oh = (blockIdx.x / tilesW) % Ho;
-  const int n = blockIdx.x / (tilesW * Ho);
-  const int ow0 = tw * TP;
+  const int th = (blockIdx.x / tilesW) % tilesH;
+  const int n = blockIdx.x / (tilesW * tilesH);
+  const int ow0 = tw * TP, oh0 = th * TH;
 
   // filter bank, pre-packed by the host as [k = c*49+kh*7+kw][co] with a zero row k = 147
+#pragma unroll 5
   for (int i = tid; i < KPAD * 16; i += 256)
     reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(w)[i];
-  // patch rows r = c*7 + kh  <->  image row ih = 2*oh - 3 + kh of plane c; columns iw = 2*ow0 - 3 + col
+  // patch row (c, pr) <-> image row ih = 2*oh0 - 3 + pr of plane c; columns iw = 2*ow0 - 3 + col
   const float* img = x + (size_t)n * 3 * H * W;
-  for (int i = tid; i < PROWS * PW; i += 256) {
+  // (independent loads, unrolled so that many are in flight before the first LDS store)
+#pragma unroll 8
+  for (int i = tid; i < 3 * PR * PW; i += 256) {
     const int r = i / PW, col = i - r * PW;
-    float v = 0.f;
-    if (r < 21) {
-      const int c = r / 7, kh = r - c * 7;
-      const int ih = 2 * oh - 3 + kh, iw = 2 * ow0 - 3 + col;
-      if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v = img[((size_t)c * H + ih) * W + iw];
-    }
-    patch[i] = v;
+    const int c = r / PR, pr = r - c * PR;
+    const int ih = 2 * oh0 - 3 + pr, iw = 2 * ow0 - 3 + col;
+    const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+    patch[i] = ok ? img[((size_t)c * H + ih) * W + iw] : 0.f;
   }
   __syncthreads();
 
   const int h = lane >> 5, l31 = lane & 31;
-  const int pix = wave * 32 + l31;             // pixel within the tile
-  int k = KHALF * h;                           // this lane half's first k
-  int kw = k % 7;
-  int offA = (k / 7) * PW + kw + 2 * pix;
-  int offB = k * 64 + l31;
-  f32x16 acc0, acc1;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-  for (int p = 0; p < KHALF; ++p) {
-    const float a = patch[offA];
-    const float b0 = wl[offB], b1 = wl[offB + 32];
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
-    if (++kw == 7) { kw = 0; offA += PW - 6; } else { offA += 1; }
-    offB += 64;
-  }
-
-  // epilogue: column j = lane&31 -> channel, row i -> pixel wave*32 + i
+  const int pix = wave * 32 + l31;             // pixel within the tile row
   const float sc0 = scale[l31], sh0 = shift[l31], sc1 = scale[l31 + 32], sh1 = shift[l31 + 32];
-  float* yrow = y + ((size_t)(n * Ho + oh) * Wo + ow0) * 64;
+  constexpr int MAXOFF = 3 * PR * PW - 1;
+
+  for (int ro = 0; ro < TH; ++ro) {
+    const int oh = oh0 + ro;
+    if (oh >= Ho) break;
+    // k = c*49 + kh*7 + kw  ->  patch offset (c*PR + 2*ro + kh)*PW + kw + 2*pix, walked incrementally
+    int k = KHALF * h;
+    int c = k / 49, rem = k - c * 49;
+    int kh = rem / 7, kw = rem - kh * 7;
+    int offA = (c * PR + 2 * ro + kh) * PW + kw + 2 * pix;
+    int offB = k * 64 + l31;
+    f32x16 acc0, acc1;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int i = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-    if (ow0 + i < Wo) {
-      const float v0 = fmaf(acc0[r], sc0, sh0), v1 = fmaf(acc1[r], sc1, sh1);
-      yrow[(size_t)i * 64 + l31] = v0 > 0.f ? v0 : 0.f;
-      yrow[(size_t)i * 64 + l31 + 32] = v1 > 0.f ? v1 : 0.f;
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    // operands for step p+1 are fetched from LDS before the MFMAs of step p issue
+    float a_n = patch[offA < MAXOFF ? offA : MAXOFF], b0_n = wl[offB], b1_n = wl[offB + 32];
+#pragma unroll 2
+    for (int p = 0; p < KHALF; ++p) {
+      const float a = a_n, b0 = b0_n, b1 = b1_n;
+      if (++kw == 7) {
+        kw = 0;
+        offA += PW - 6;
+        if (++kh == 7) { kh = 0; offA += (PR - 7) * PW; }
+      } else {
+        offA += 1;
+      }
+      offB += 64;
+      const int oa = offA < MAXOFF ? offA : MAXOFF, ob = offB < (KPAD - 1) * 64 + 32 ? offB : (KPAD - 1) * 64;
+      a_n = patch[oa]; b0_n = wl[ob]; b1_n = wl[ob + 32];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+    }
+    // epilogue: column j = lane&31 -> channel, row i -> pixel wave*32 + i
+    float* yrow = y + ((size_t)(n * Ho + oh) * Wo + ow0) * 64;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (ow0 + i < Wo) {
+        const float v0 = fmaf(acc0[r], sc0, sh0), v1 = fmaf(acc1[r], sc1, sh1);
+        yrow[(size_t)i * 64 + l31] = v0 > 0.f ? v0 : 0.f;
+        yrow[(size_t)i * 64 + l31 + 32] = v1 > 0.f ? v1 : 0.f;
+      }
     }
   }
 }
+
+constexpr size_t kStemLds = (size_t)(KPAD * 64 + 3 * PR * PW) * sizeof(float);
 
 // 3x3 stride-2 pad-1 max-pool on NHWC, 4 channels per thread.  ref src/encoders.py:157.
 __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc(const float* __restrict__ x, float* __restrict__ y, int N,
@@ -114,11 +137,17 @@ extern "C" int bevf_stem_conv7x7_f32(const float* x, const float* w, const float
   BEVF_REQUIRE(bevf_aligned16(w), "stem: packed filter bank must be 16-byte aligned");
   BEVF_REQUIRE(N > 0 && H >= 1 && W >= 1, "stem: empty shape");
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
-  const int tilesW = (Wo + TP - 1) / TP;
-  const long long grid = (long long)N * Ho * tilesW;
+  const int tilesW = (Wo + TP - 1) / TP, tilesH = (Ho + TH - 1) / TH;
+  const long long grid = (long long)N * tilesH * tilesW;
   BEVF_REQUIRE(grid < (1ll << 31), "stem: grid too large");
-  hipLaunchKernelGGL(stem_conv7x7_f32, dim3((unsigned)grid), dim3(256), 0, static_cast<hipStream_t>(stream), x, w,
-                     scale, shift, y, H, W, Ho, Wo, tilesW);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_conv7x7_f32),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStemLds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(stem_conv7x7_f32, dim3((unsigned)grid), dim3(256), kStemLds, static_cast<hipStream_t>(stream), x,
+                     w, scale, shift, y, H, W, Ho, Wo, tilesW, tilesH);
   return bevf_check_launch("bevf_stem_conv7x7_f32");
 }
 
