@@ -2,27 +2,48 @@
 // on v_mfma_f32_32x32x2_f32.  ref src/encoders.py:154-156.
 //
 // One workgroup = TH = 4 output rows x 128 pixels x all 64 channels.  The 3 x (2*TH+5) input
-// rows it needs (261 columns) are staged once in LDS straight from the NCHW image (coalesced
-// along W, zero-filled outside the image); the whole filter bank sits beside it as
-// [k][channel] (packed once by the host) so the B-operand reads are conflict-free, and is
-// amortised over the four rows.  The A operand is read element-wise out of the patch:
-// A[pixel i of row ro][k=(c,kh,kw)] = patch[c][2*ro + kh][2*i + kw].
-// K = 147 is padded to 148 and split in two halves of 74: lane half h walks k = p + 74*h
-// (the padded k = 147 has a zero filter row; its A address is clamped into the patch).
+// rows it needs are staged once in LDS straight from the NCHW image (16-B loads along W,
+// zero-filled outside the image); the whole filter bank sits beside it as [k][channel] (packed
+// once by the host) so the B-operand reads are conflict-free, and is amortised over the rows.
+// The A operand is read element-wise out of the patch:
+//     A[pixel i of row ro][k=(c,kh,kw)] = patch[c][2*ro + kh][2*i + kw + 1]
+// (patch column 0 is image column 2*ow0 - 4, which keeps the 16-B loads aligned).
+//
+// v_mfma_f32_32x32x2_f32 consumes two k per step (lane half h takes one each) and runs at the
+// fp32 VALU rate, so the k loop must not spend VALU on addresses.  The 147 taps are therefore
+// paired so that the h=1 tap is the h=0 tap shifted by a constant: 63 pairs one patch row apart
+// (kh, kh+1), 9 pairs one column apart in the kh=6 row, one pair a channel apart, and the last
+// tap alone against a zero filter row.  Each step's addresses are then "per-group base VGPR
+// (holding the h shift) + compile-time immediate", fully unrolled: 3 ds_read_b32 + 2 MFMA per step.
 #include "common.h"
 
 namespace {
 
 constexpr int TP = 128;              // output pixels per workgroup row (along W)
 constexpr int TH = 4;                // output rows per workgroup
-constexpr int PW = 2 * TP + 8;       // patch row pitch (261 used)
+constexpr int PW = 2 * TP + 8;       // patch row pitch in floats (cols 1..261 used)
 constexpr int PR = 2 * TH + 5;       // patch rows per input channel
-constexpr int KPAD = 148, KHALF = 74;
+constexpr int KPAD = 148, NSTEP = 74;
+
+struct StemStep { int a_imm, b_imm, grp; };
+__host__ __device__ constexpr StemStep stem_step(int p) {
+  if (p < 63) {                                     // (c,kh,kw) | (c,kh+1,kw), kh even
+    const int c = p / 21, r = p % 21, kh = 2 * (r / 7), kw = r % 7;
+    return {((c * PR + kh) * PW + kw + 1) * 4, (c * 49 + kh * 7 + kw) * 256, 0};
+  }
+  if (p < 72) {                                     // (c,6,kw) | (c,6,kw+1), kw even
+    const int q = p - 63, c = q / 3, kw = 2 * (q % 3);
+    return {((c * PR + 6) * PW + kw + 1) * 4, (c * 49 + 42 + kw) * 256, 1};
+  }
+  if (p == 72) return {((0 * PR + 6) * PW + 6 + 1) * 4, 48 * 256, 2};          // (0,6,6) | (1,6,6)
+  return {((2 * PR + 6) * PW + 6 + 1) * 4, 146 * 256, 3};                      // (2,6,6) | zero row 147
+}
 
 __global__ __launch_bounds__(256) void stem_conv7x7_f32(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift, float* __restrict__ y,
-                                                         int H, int W, int Ho, int Wo, int tilesW, int tilesH) {
+                                                         int H, int W, int Ho, int Wo, int tilesW, int tilesH,
+                                                         int vec_ok) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* wl = smem;                      // [KPAD][64]
   float* patch = smem + KPAD * 64;       // [3][PR][PW]
@@ -37,53 +58,76 @@ __global__ __launch_bounds__(256) void stem_conv7x7_f32(const float* __restrict_
 #pragma unroll 5
   for (int i = tid; i < KPAD * 16; i += 256)
     reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(w)[i];
-  // patch row (c, pr) <-> image row ih = 2*oh0 - 3 + pr of plane c; columns iw = 2*ow0 - 3 + col
+  // patch row (c, pr) <-> image row ih = 2*oh0 - 3 + pr of plane c; patch col <-> iw = 2*ow0 - 4 + col
   const float* img = x + (size_t)n * 3 * H * W;
-  // (independent loads, unrolled so that many are in flight before the first LDS store)
+  const int iw0 = 2 * ow0 - 4;
+  if (vec_ok) {                          // W % 4 == 0 and 16-B aligned rows: whole float4s are in or out
+#pragma unroll 4
+    for (int i = tid; i < 3 * PR * (PW / 4); i += 256) {
+      const int r = i / (PW / 4), c4 = i - r * (PW / 4);
+      const int c = r / PR, pr = r - c * PR;
+      const int ih = 2 * oh0 - 3 + pr, iw = iw0 + 4 * c4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+        v = *reinterpret_cast<const f32x4*>(img + ((size_t)c * H + ih) * W + iw);
+      reinterpret_cast<f32x4*>(patch)[i] = v;
+    }
+  } else {
 #pragma unroll 8
-  for (int i = tid; i < 3 * PR * PW; i += 256) {
-    const int r = i / PW, col = i - r * PW;
-    const int c = r / PR, pr = r - c * PR;
-    const int ih = 2 * oh0 - 3 + pr, iw = 2 * ow0 - 3 + col;
-    const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-    patch[i] = ok ? img[((size_t)c * H + ih) * W + iw] : 0.f;
+    for (int i = tid; i < 3 * PR * PW; i += 256) {
+      const int r = i / PW, col = i - r * PW;
+      const int c = r / PR, pr = r - c * PR;
+      const int ih = 2 * oh0 - 3 + pr, iw = iw0 + col;
+      const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+      patch[i] = ok ? img[((size_t)c * H + ih) * W + iw] : 0.f;
+    }
   }
   __syncthreads();
 
   const int h = lane >> 5, l31 = lane & 31;
   const int pix = wave * 32 + l31;             // pixel within the tile row
   const float sc0 = scale[l31], sh0 = shift[l31], sc1 = scale[l31 + 32], sh1 = shift[l31 + 32];
-  constexpr int MAXOFF = 3 * PR * PW - 1;
+  const char* const bb = reinterpret_cast<const char*>(wl) + l31 * 4;
+  const char* const pb[3] = {bb + h * 7 * 256, bb + h * 256, bb + h * 49 * 256};
 
   for (int ro = 0; ro < TH; ++ro) {
     const int oh = oh0 + ro;
     if (oh >= Ho) break;
-    // k = c*49 + kh*7 + kw  ->  patch offset (c*PR + 2*ro + kh)*PW + kw + 2*pix, walked incrementally
-    int k = KHALF * h;
-    int c = k / 49, rem = k - c * 49;
-    int kh = rem / 7, kw = rem - kh * 7;
-    int offA = (c * PR + 2 * ro + kh) * PW + kw + 2 * pix;
-    int offB = k * 64 + l31;
+    const char* const ab = reinterpret_cast<const char*>(patch) + (2 * ro * PW + 2 * pix) * 4;
+    const char* const pa[4] = {ab + h * PW * 4, ab + h * 4, ab + h * PR * PW * 4, ab};
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    // operands for step p+1 are fetched from LDS before the MFMAs of step p issue
-    float a_n = patch[offA < MAXOFF ? offA : MAXOFF], b0_n = wl[offB], b1_n = wl[offB + 32];
-#pragma unroll 2
-    for (int p = 0; p < KHALF; ++p) {
-      const float a = a_n, b0 = b0_n, b1 = b1_n;
-      if (++kw == 7) {
-        kw = 0;
-        offA += PW - 6;
-        if (++kh == 7) { kh = 0; offA += (PR - 7) * PW; }
-      } else {
-        offA += 1;
+    // software pipeline over chunks of 4 steps: the 12 operand reads of chunk c+1 are issued before
+    // the 8 MFMAs of chunk c (two register sets, statically indexed), so LDS latency hides under MFMA
+    constexpr int CH = 4, NCH = (NSTEP + CH - 1) / CH;
+    float av[2][CH], b0v[2][CH], b1v[2][CH];
+    auto load_chunk = [&](int cidx, int set) {
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int p = cidx * CH + u;
+        if (p < NSTEP) {
+          const StemStep st = stem_step(p);
+          const char* const bp = pb[st.grp == 3 ? 1 : st.grp];
+          av[set][u] = *reinterpret_cast<const float*>(pa[st.grp] + st.a_imm);
+          b0v[set][u] = *reinterpret_cast<const float*>(bp + st.b_imm);
+          b1v[set][u] = *reinterpret_cast<const float*>(bp + st.b_imm + 128);
+        }
       }
-      offB += 64;
-      const int oa = offA < MAXOFF ? offA : MAXOFF, ob = offB < (KPAD - 1) * 64 + 32 ? offB : (KPAD - 1) * 64;
-      a_n = patch[oa]; b0_n = wl[ob]; b1_n = wl[ob + 32];
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+    };
+    load_chunk(0, 0);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      if (c + 1 < NCH) load_chunk(c + 1, (c + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        if (c * CH + u < NSTEP) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c & 1][u], b0v[c & 1][u], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c & 1][u], b1v[c & 1][u], acc1, 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     // epilogue: column j = lane&31 -> channel, row i -> pixel wave*32 + i
     float* yrow = y + ((size_t)(n * Ho + oh) * Wo + ow0) * 64;
@@ -147,7 +191,7 @@ extern "C" int bevf_stem_conv7x7_f32(const float* x, const float* w, const float
     attr_done = true;
   }
   hipLaunchKernelGGL(stem_conv7x7_f32, dim3((unsigned)grid), dim3(256), kStemLds, static_cast<hipStream_t>(stream), x,
-                     w, scale, shift, y, H, W, Ho, Wo, tilesW, tilesH);
+                     w, scale, shift, y, H, W, Ho, Wo, tilesW, tilesH, (W % 4 == 0 && bevf_aligned16(x)) ? 1 : 0);
   return bevf_check_launch("bevf_stem_conv7x7_f32");
 }
 
