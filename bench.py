@@ -51,10 +51,23 @@ def make_inputs(cfg, batch, seed, dev):
             [r.to(dev) for r in radars] if radars else None)
 
 
+def host_cores() -> int:
+    """Cores this process may really use: min(affinity, cgroup cpu.max quota) -- the GPU box reports 256
+    logical CPUs but grants a 16-CPU share; oversubscribing it makes the CPU baseline meaninglessly slow."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(cfg, state_dict, budget_s=12.0):
     """The oracle (CPU restatement, oracle/ref_model.py) on the host cores, B=1, same synthetic frame."""
     from oracle import ref_model
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     ora = ref_model.make_detector(cfg["modality"], cfg["bev"], cfg["bev"])
     ora.load_state_dict(state_dict)

@@ -47,6 +47,21 @@ class DecodeDesc(C.Structure):
                [(n, C.c_float) for n in ("thresh", "voxel", "x_min", "y_min")]
 
 
+class TargetsDesc(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("boxes", "labels", "has_vel", "heatmap", "offset", "size", "rot", "vel",
+                                          "mask", "ind", "reg_mask", "target_offset", "target_size", "target_rot",
+                                          "target_vel", "owner_scratch")] + \
+               [(n, C.c_int32) for n in ("B", "nmax", "H", "W", "C", "max_objects", "min_radius")] + \
+               [("pc_range", C.c_float * 6), ("gaussian_overlap", C.c_float)]
+
+
+class LossDesc(C.Structure):
+    _fields_ = [("pred_heatmap", C.c_void_p), ("tgt_heatmap", C.c_void_p), ("pred_reg", C.c_void_p * 4),
+                ("tgt_reg", C.c_void_p * 4), ("ind", C.c_void_p), ("reg_mask", C.c_void_p), ("work", C.c_void_p),
+                ("out", C.c_void_p)] + [(n, C.c_int32) for n in ("B", "C", "H", "W", "K")] + \
+               [("weights", C.c_float * 5)]
+
+
 _lib: Optional[C.CDLL] = None
 
 # name -> (restype, argtypes); the not-gpu test checks every one is exported by the .so
@@ -69,6 +84,10 @@ SIGNATURES = {
     "bevf_fill_f32": (C.c_int, [C.c_void_p, C.c_float, C.c_size_t, C.c_void_p]),
     "bevf_centernet_decode_work_bytes": (C.c_size_t, [C.c_int] * 5),
     "bevf_centernet_decode_f32": (C.c_int, [C.POINTER(DecodeDesc), C.c_void_p]),
+    "bevf_centernet_targets_f32": (C.c_int, [C.POINTER(TargetsDesc), C.c_void_p]),
+    "bevf_nms_keep_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 3 + [C.c_void_p]),
+    "bevf_centernet_loss_work_floats": (C.c_size_t, []),
+    "bevf_centernet_loss_f32": (C.c_int, [C.POINTER(LossDesc), C.c_void_p]),
 }
 
 
@@ -255,3 +274,73 @@ def centernet_decode(pred: dict, K: int, thresh: float, voxel: float, x_min: flo
                    _p(work, torch.uint8), B, Cn, H, W, K, int(true_labels), thresh, voxel, x_min, y_min)
     _check(lib().bevf_centernet_decode_f32(C.byref(d), _stream()), "bevf_centernet_decode_f32")
     return boxes, scores, labels, vels, count
+
+
+def nms_keep(heat: torch.Tensor, out: torch.Tensor, planes: int, H: int, W: int):
+    if heat.numel() != planes * H * W or out.numel() != planes * H * W:
+        raise BevfError("nms_keep: buffer sizes do not match planes,H,W")
+    _check(lib().bevf_nms_keep_f32(_pc(heat), _pc(out), planes, H, W, _stream()), "bevf_nms_keep_f32")
+
+
+def centernet_targets(boxes, labels, has_vel, out: dict, B: int, nmax: int, H: int, W: int, Cn: int,
+                      max_objects: int, pc_range, overlap: float, min_radius: int):
+    dev = boxes.device
+    if tuple(boxes.shape) != (B, nmax, 9) or tuple(labels.shape) != (B, nmax) or has_vel.numel() != B:
+        raise BevfError("targets: boxes must be (B,nmax,9), labels (B,nmax), has_vel (B,)")
+    want = dict(heatmap=(B, Cn, H, W), offset=(B, 2, H, W), size=(B, 3, H, W), rot=(B, 2, H, W), vel=(B, 2, H, W),
+                mask=(B, max_objects), ind=(B, max_objects), reg_mask=(B, max_objects),
+                target_offset=(B, max_objects, 2), target_size=(B, max_objects, 3), target_rot=(B, max_objects, 2),
+                target_vel=(B, max_objects, 2))
+    for k, shp in want.items():
+        if tuple(out[k].shape) != shp:
+            raise BevfError(f"targets: output {k} has shape {tuple(out[k].shape)}, expected {shp}")
+    owner = torch.zeros(B, H * W, dtype=torch.int32, device=dev)
+    d = TargetsDesc()
+    d.boxes, d.labels, d.has_vel = _pc(boxes), _pc(labels, torch.int32), _pc(has_vel, torch.int32)
+    for k in ("heatmap", "offset", "size", "rot", "vel", "target_offset", "target_size", "target_rot", "target_vel"):
+        setattr(d, k, _pc(out[k]))
+    d.mask, d.reg_mask, d.ind = _pc(out["mask"], torch.uint8), _pc(out["reg_mask"], torch.uint8), _pc(out["ind"], torch.int64)
+    d.owner_scratch = _pc(owner, torch.int32)
+    d.B, d.nmax, d.H, d.W, d.C, d.max_objects, d.min_radius = B, nmax, H, W, Cn, max_objects, min_radius
+    for i in range(6):
+        d.pc_range[i] = float(pc_range[i])
+    d.gaussian_overlap = overlap
+    _check(lib().bevf_centernet_targets_f32(C.byref(d), _stream()), "bevf_centernet_targets_f32")
+
+
+def centernet_loss(pred: dict, tgt: dict, weights) -> torch.Tensor:
+    heat = pred["heatmap"]
+    B, Cn, H, W = heat.shape
+    K = tgt["ind"].shape[1]
+    dev = heat.device
+    if tuple(tgt["heatmap"].shape) != (B, Cn, H, W):
+        raise BevfError("loss: target heatmap shape differs from the prediction")
+    d = LossDesc()
+    keep = []
+
+    def f32(t):
+        t = t.float().contiguous()
+        keep.append(t)
+        return _pc(t)
+    d.pred_heatmap, d.tgt_heatmap = f32(heat), f32(tgt["heatmap"])
+    for q, (name, c) in enumerate((("offset", 2), ("size", 3), ("rot", 2), ("vel", 2))):
+        if tuple(pred[name].shape) != (B, c, H, W) or tuple(tgt["target_" + name].shape) != (B, K, c):
+            raise BevfError(f"loss: {name} shapes wrong")
+        d.pred_reg[q], d.tgt_reg[q] = f32(pred[name]), f32(tgt["target_" + name])
+    ind = tgt["ind"].to(torch.int64).contiguous()
+    rm = tgt["reg_mask"].to(torch.uint8).contiguous()
+    if int(ind.numel()) != B * K or rm.numel() != B * K:
+        raise BevfError("loss: ind / reg_mask must be (B,K)")
+    work = torch.empty(lib().bevf_centernet_loss_work_floats(), device=dev)
+    out = torch.empty(6, device=dev)
+    d.ind, d.reg_mask, d.work, d.out = _pc(ind, torch.int64), _pc(rm, torch.uint8), _pc(work), _pc(out)
+    d.B, d.C, d.H, d.W, d.K = B, Cn, H, W, K
+    for i in range(5):
+        d.weights[i] = float(weights[i])
+    _check(lib().bevf_centernet_loss_f32(C.byref(d), _stream()), "bevf_centernet_loss_f32")
+    return out
+
+
+def centernet_decode_raw(pred: dict, K: int):
+    """Top-K bookkeeping only: voxel 1, origin 0, zero offsets -> boxes[...,0:2] are the integer (x, y) cells."""
+    return centernet_decode(pred, K, -1.0, 1.0, 0.0, 0.0, False)

@@ -1,0 +1,127 @@
+"""Drop-in for the reference's `centernet_target` module (ref src/centernet_target.py), on device.
+
+* `prepare_centernet_targets` -- one kernel launch for the whole batch (the reference loops over
+  objects on the host and round-trips the heatmap device->numpy->device per object, ref :278-280).
+* `CenterNetLoss` -- focal + gather-L1 reductions on device, including the reference's second
+  sigmoid on the already-sigmoided heatmap (ref :563).
+* `decode_centernet_predictions` -- keep mask, two-level top-K, gather and box assembly on device;
+  voxel size 2.048 m (ref :389).  `labels` are always 0 exactly like the reference (ref :434);
+  pass `true_labels=True` for the class of the winning heatmap plane.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import engine as E
+
+PC_RANGE = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
+
+
+def _decode(predictions: Dict[str, torch.Tensor], score_thresh: float, max_detections: int, voxel_size: float,
+            true_labels: bool = False) -> List[Dict[str, torch.Tensor]]:
+    heat = predictions["heatmap"]
+    E.require_cuda(heat)
+    pred = {k: predictions[k].float().contiguous() for k in ("heatmap", "offset", "size", "rot", "vel")}
+    boxes, scores, labels, vels, count = L.centernet_decode(pred, max_detections, float(score_thresh),
+                                                            float(voxel_size), PC_RANGE[0], PC_RANGE[1], true_labels)
+    counts = count.cpu().tolist()                     # the reference syncs here too (mask.sum() == 0, ref :362)
+    out = []
+    for b, n in enumerate(counts):
+        if n == 0:                                    # ref :363-368 returns CPU zeros for an empty frame
+            out.append({"boxes": torch.zeros(0, 7), "scores": torch.zeros(0),
+                        "labels": torch.zeros(0, dtype=torch.long), "velocities": torch.zeros(0, 2)})
+        else:
+            out.append({"boxes": boxes[b, :n], "scores": scores[b, :n], "labels": labels[b, :n],
+                        "velocities": vels[b, :n]})
+    return out
+
+
+def decode_centernet_predictions(predictions: Dict[str, torch.Tensor], score_thresh: float = 0.3,
+                                 max_detections: int = 100, true_labels: bool = False) -> List[Dict[str, torch.Tensor]]:
+    """ref src/centernet_target.py:326-413 (2.048 m cells)."""
+    return _decode(predictions, score_thresh, max_detections, 2.048, true_labels)
+
+
+def _nms(heat: torch.Tensor, kernel: int = 3) -> torch.Tensor:
+    """ref :416-421 -- heat * (maxpool3x3(heat) == heat).  Device tensor in, device tensor out."""
+    if kernel != 3:
+        raise NotImplementedError("only the 3x3 keep mask of the reference is built")
+    E.require_cuda(heat)
+    out = torch.empty_like(heat, dtype=torch.float32)
+    B, C, H, W = heat.shape
+    L.nms_keep(heat.float().contiguous(), out, B * C, H, W)
+    return out
+
+
+def gaussian_radius(det_size: Tuple[float, float], min_overlap: float = 0.7) -> float:
+    """ref :128-150 (host helper kept for API parity; the device kernel evaluates the same expression)."""
+    import numpy as np
+    height, width = det_size
+    b1 = height + width
+    r1 = (b1 + np.sqrt(b1 ** 2 - 4 * (width * height * (1 - min_overlap) / (1 + min_overlap)))) / 2
+    b2 = 2 * (height + width)
+    r2 = (b2 + np.sqrt(b2 ** 2 - 16 * ((1 - min_overlap) * width * height))) / 2
+    a3, b3 = 4 * min_overlap, -2 * min_overlap * (height + width)
+    r3 = (b3 + np.sqrt(b3 ** 2 - 4 * a3 * ((min_overlap - 1) * width * height))) / 2
+    return min(r1, r2, r3)
+
+
+def prepare_centernet_targets(batch: Dict, device: torch.device, pc_range: Optional[List[float]] = None,
+                              bev_size: Tuple[int, int] = (50, 50), num_classes: int = 10, max_objects: int = 500,
+                              gaussian_overlap: float = 0.7, min_radius: int = 2) -> Dict[str, torch.Tensor]:
+    """ref :170-324.  batch['gt_boxes'] / ['gt_labels']: per-frame (M,7|9) boxes and (M,) labels (-1 = padding),
+    lists or stacked tensors.  Returns the reference's 12 target tensors, computed by one kernel launch."""
+    if pc_range is None:
+        pc_range = PC_RANGE
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise L.BevfError("prepare_centernet_targets runs on the GPU: pass device='cuda' (no CPU fallback)")
+    boxes_l, labels_l = batch["gt_boxes"], batch["gt_labels"]
+    B = len(boxes_l)
+    H, W = bev_size
+    nmax = max([min(len(b), max_objects) for b in boxes_l] + [1])
+    bc = max([b.shape[1] if hasattr(b, "shape") and len(b.shape) == 2 and len(b) else 7 for b in boxes_l] + [7])
+    bc = 9 if bc > 7 else 7
+    boxes = torch.zeros(B, nmax, 9, dtype=torch.float32)
+    labels = torch.full((B, nmax), -1, dtype=torch.int32)
+    has_vel = torch.zeros(B, dtype=torch.int32)
+    for b in range(B):
+        bb = torch.as_tensor(boxes_l[b]).detach().float().cpu()
+        ll = torch.as_tensor(labels_l[b]).detach().cpu()
+        n = min(len(bb), max_objects)
+        if n:
+            boxes[b, :n, :min(bb.shape[1], 9)] = bb[:n, :9]
+            labels[b, :n] = ll[:n].to(torch.int32)
+            has_vel[b] = 1 if bb.shape[1] > 7 else 0
+    f = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
+    out = dict(heatmap=f(B, num_classes, H, W), offset=f(B, 2, H, W), size=f(B, 3, H, W), rot=f(B, 2, H, W),
+               vel=f(B, 2, H, W), mask=torch.zeros(B, max_objects, dtype=torch.uint8, device=device),
+               ind=torch.zeros(B, max_objects, dtype=torch.long, device=device),
+               reg_mask=torch.zeros(B, max_objects, dtype=torch.uint8, device=device),
+               target_offset=f(B, max_objects, 2), target_size=f(B, max_objects, 3),
+               target_rot=f(B, max_objects, 2), target_vel=f(B, max_objects, 2))
+    L.centernet_targets(boxes.to(device), labels.to(device), has_vel.to(device), out, B, nmax, H, W, num_classes,
+                        max_objects, pc_range, float(gaussian_overlap), int(min_radius))
+    return out
+
+
+class CenterNetLoss(nn.Module):
+    """ref :455-622.  weights 1,1,1,1,0.1 (the YAML's loss_weights are unread in the reference, ref :460-467)."""
+
+    def __init__(self, heatmap_weight: float = 1.0, offset_weight: float = 1.0, size_weight: float = 1.0,
+                 rot_weight: float = 1.0, vel_weight: float = 0.1):
+        super().__init__()
+        self.heatmap_weight, self.offset_weight = heatmap_weight, offset_weight
+        self.size_weight, self.rot_weight, self.vel_weight = size_weight, rot_weight, vel_weight
+
+    @torch.no_grad()
+    def forward(self, predictions: Dict[str, torch.Tensor], targets: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        E.require_cuda(predictions["heatmap"], targets["heatmap"])
+        w = (self.heatmap_weight, self.offset_weight, self.size_weight, self.rot_weight, self.vel_weight)
+        vals = L.centernet_loss(predictions, targets, w)            # (6,) device tensor
+        names = ("total_loss", "heatmap_loss", "offset_loss", "size_loss", "rot_loss", "vel_loss")
+        return {n: vals[i] for i, n in enumerate(names)}

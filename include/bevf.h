@@ -167,6 +167,51 @@ typedef struct {
 size_t bevf_centernet_decode_work_bytes(int B, int C, int H, int W, int K);
 int bevf_centernet_decode_f32(const bevf_decode_desc* d, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training targets, ref src/centernet_target.py:170-324 (+ gaussian_radius :128-150, gaussian_2d :118-125,
+ * draw_gaussian :152-168): one workgroup per frame.  boxes are float32 [B][nmax][9] (x,y,z,w,l,h,yaw,vx,vy;
+ * the last two ignored unless has_vel[b]), labels int32 (-1 or >= C skips the object, like the padding of
+ * ref src/train_detect.py).  Grid index / radius arithmetic is fp32 in the reference's own operation order
+ * (bit-exact ind / mask / reg_mask); the gaussian is float64 rounded to fp32; dense maps keep the LAST object
+ * of a cell, as the reference's sequential writes do.  All outputs must be zero-filled by the caller.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* boxes;
+  const int32_t* labels;
+  const int32_t* has_vel;        /* [B] */
+  float* heatmap;                /* (B,C,H,W) */
+  float* offset; float* size; float* rot; float* vel;      /* (B,2|3|2|2,H,W) */
+  uint8_t* mask; int64_t* ind; uint8_t* reg_mask;          /* [B][max_objects] */
+  float* target_offset; float* target_size; float* target_rot; float* target_vel;   /* [B][max_objects][2|3|2|2] */
+  int32_t* owner_scratch;        /* [B][H*W] int32, zero-filled */
+  int32_t B, nmax, H, W, C, max_objects, min_radius;
+  float pc_range[6];
+  float gaussian_overlap;
+} bevf_targets_desc;
+int bevf_centernet_targets_f32(const bevf_targets_desc* d, void* stream);
+
+/* _nms of ref src/centernet_target.py:416-421: out = heat * (maxpool3x3(heat) == heat), planes = B*C.  */
+int bevf_nms_keep_f32(const float* heat, float* out, int planes, int H, int W, void* stream);
+
+/* CenterNetLoss.forward, ref src/centernet_target.py:476-622: penalty-reduced focal loss on
+ * clamp(sigmoid(pred)) -- the reference applies sigmoid to the already-sigmoided head output and so does
+ * this -- and mask-weighted gather-L1 for offset/size/rot/vel.  out[6] = total, heatmap, offset, size, rot,
+ * vel.  Two launches (fixed-grid partial sums, then a fixed-order final sum): deterministic.            */
+typedef struct {
+  const float* pred_heatmap;     /* (B,C,H,W) */
+  const float* tgt_heatmap;
+  const float* pred_reg[4];      /* offset,size,rot,vel (B,c,H,W) */
+  const float* tgt_reg[4];       /* target_offset,... [B][K][c] */
+  const int64_t* ind;            /* [B][K] */
+  const uint8_t* reg_mask;       /* [B][K] */
+  float* work;                   /* bevf_centernet_loss_work_floats() floats */
+  float* out;                    /* [6] */
+  int32_t B, C, H, W, K;
+  float weights[5];              /* heatmap, offset, size, rot, vel */
+} bevf_loss_desc;
+size_t bevf_centernet_loss_work_floats(void);
+int bevf_centernet_loss_f32(const bevf_loss_desc* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
