@@ -23,7 +23,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from bevfusion_multimodal_3d_object_detection_amd import engine, fusion, synth   # noqa: E402
+from bevfusion_multimodal_3d_object_detection_amd import engine, fusion, replicas, synth   # noqa: E402
 
 CONFIGS = {
     # BASELINE.json configs[0..2]; (modality, cams, H, W, points, radars, bev)
@@ -49,6 +49,18 @@ def make_inputs(cfg, batch, seed, dev):
                                            cfg["radars"], 125, 7, seed=seed)
     return (imgs.to(dev) if imgs is not None else None, pts.to(dev) if pts is not None else None,
             [r.to(dev) for r in radars] if radars else None)
+
+
+def pmc_traffic(config: int, batch: int):
+    """HBM-side bytes per conv launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, see
+    tools/pmc_summary.py); only valid for the configuration the profile was taken on."""
+    path = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_config{config}_b{batch}.json")
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    n = sum(v["launches"] for k, v in d.items() if k.startswith("conv_igemm"))
+    tot = sum(v["launches"] * v["hbm_bytes_per_launch"] for k, v in d.items() if k.startswith("conv_igemm"))
+    return (tot / n, os.path.relpath(path, ROOT)) if n else None
 
 
 def host_cores() -> int:
@@ -96,22 +108,17 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true", help="skip the per-launch HIP-event brackets")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, world = replicas.rank_world()
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+    dist = replicas.init("nccl", dev)              # RCCL; only for the barrier and the MAX of the elapsed time
     cfg = CONFIGS[args.config]
 
     model_cpu = build_model(cfg)
     state = {k: v.clone() for k, v in model_cpu.state_dict().items()}
     model = model_cpu.to(dev)
-    inputs = make_inputs(cfg, args.batch, 0x5EED + 1000 * args.config + rank, dev)
+    inputs = make_inputs(cfg, args.batch, replicas.frame_seed(0x5EED, args.config, rank), dev)
 
     def step():
         return model(*inputs)
@@ -123,26 +130,21 @@ def main():
 
     timer = None if args.no_kernel_timer else engine.KernelTimer()
     engine.set_timer(timer)
-    if dist is not None:
-        dist.barrier()
+    replicas.barrier(dist)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    replicas.barrier(dist)
     elapsed = time.perf_counter() - t0
     engine.set_timer(None)
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = replicas.max_over_ranks(elapsed, dist, dev)
 
     if rank == 0:
-        frames = world * args.batch * args.steps
         line = {
-            "metric": "BEV frames/sec (6-cam+LiDAR, 128x128 BEV)", "value": frames / elapsed, "unit": "frames/s",
+            "metric": "BEV frames/sec (6-cam+LiDAR, 128x128 BEV)",
+            "value": replicas.aggregate_fps(args.batch * args.steps, world, elapsed), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
@@ -155,11 +157,15 @@ def main():
             if conv:
                 ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
                 line["roofline"] = {"kernel": "conv_igemm_f32", "bound": "mfma", "achieved": ach,
+                                    "traffic_source": None,
                                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
                                     "traffic": None, "launches_per_step": conv["launches"] / args.steps,
                                     "avg_launch_ms": conv["ms"] / conv["launches"],
                                     "gflop_per_step": conv["flops"] / args.steps / 1e9,
                                     "share_of_step": conv["ms"] / (1e3 * elapsed)}
+                tr = pmc_traffic(args.config, args.batch)
+                if tr is not None:
+                    line["roofline"]["traffic"], line["roofline"]["traffic_source"] = tr
             pool = tot.get("bev_pool")
             if pool:
                 gbs = pool["bytes"] / (pool["ms"] * 1e-3) / 1e9

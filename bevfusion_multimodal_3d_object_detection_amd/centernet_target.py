@@ -125,3 +125,9 @@ class CenterNetLoss(nn.Module):
         vals = L.centernet_loss(predictions, targets, w)            # (6,) device tensor
         names = ("total_loss", "heatmap_loss", "offset_loss", "size_loss", "rot_loss", "vel_loss")
         return {n: vals[i] for i, n in enumerate(names)}
+
+
+def _topk(scores: torch.Tensor, K: int = 100):
+    """ref :424-452 (see fusion_detection._topk)."""
+    from .fusion_detection import _topk as impl
+    return impl(scores, K)

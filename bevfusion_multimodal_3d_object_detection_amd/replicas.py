@@ -1,0 +1,54 @@
+"""Frame sharding for multi-GPU inference: independent replicas, one process per GPU, no data-path
+collective.  torch.distributed (RCCL on ROCm, gloo in the CPU tests) is used only to
+line the ranks up and to take the MAX over ranks of the elapsed time."""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Tuple
+
+import torch
+
+
+def rank_world() -> Tuple[int, int, int]:
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init(backend: str, device: Optional[torch.device] = None):
+    """Returns the torch.distributed module when WORLD_SIZE > 1, else None."""
+    _, _, world = rank_world()
+    if world <= 1:
+        return None
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        dist.init_process_group(backend, **kw)
+    return dist
+
+
+def shard_frames(n_frames: int, rank: int, world: int) -> List[int]:
+    """Static round-robin of frame indices over ranks (frames are independent)."""
+    return list(range(rank, n_frames, world))
+
+
+def frame_seed(base: int, config: int, frame: int) -> int:
+    """seed = base + 1000*config + frame index (identical on every machine)."""
+    return base + 1000 * config + frame
+
+
+def barrier(dist) -> None:
+    if dist is not None:
+        dist.barrier()
+
+
+def max_over_ranks(value: float, dist, device: torch.device) -> float:
+    if dist is None:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def aggregate_fps(frames_per_rank: int, world: int, elapsed_max_s: float) -> float:
+    """Whole-job throughput: all ranks' frames over the slowest rank's time."""
+    return world * frames_per_rank / elapsed_max_s

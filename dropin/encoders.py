@@ -1,0 +1,7 @@
+"""Drop-in shim: `import encoders` resolves to the MI355X-native module (put this directory on PYTHONPATH
+in place of the reference's src/).  See INTEGRATION.md."""
+import os as _os
+import sys as _sys
+
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+from bevfusion_multimodal_3d_object_detection_amd.encoders import *  # noqa: F401,F403,E402

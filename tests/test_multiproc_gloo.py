@@ -1,0 +1,55 @@
+"""world_size-2 gloo test of the N>1 path bench.py uses (frame sharding + barrier + MAX over ranks). CPU only."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+from bevfusion_multimodal_3d_object_detection_amd import replicas
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    dist = replicas.init("gloo")
+    assert dist is not None and dist.get_world_size() == world
+    frames = replicas.shard_frames(11, rank, world)
+    replicas.barrier(dist)
+    elapsed = replicas.max_over_ranks(1.0 + rank, dist, torch.device("cpu"))       # rank 1 is the slow one
+    # every rank regenerates its own frames from (seed, index): check two ranks never share a seed
+    seeds = [replicas.frame_seed(0x5EED, 2, f) for f in frames]
+    q.put((rank, frames, elapsed, seeds))
+    replicas.barrier(dist)
+    dist.destroy_process_group()
+
+
+def test_two_rank_replicas_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    all_frames = sorted(f for _, fr, _, _ in got for f in fr)
+    assert all_frames == list(range(11))                                  # a partition, nothing lost or duplicated
+    assert all(e == 2.0 for _, _, e, _ in got)                            # MAX over ranks, identical everywhere
+    assert len({s for _, _, _, ss in got for s in ss}) == 11
+    assert replicas.aggregate_fps(40, 2, 2.0) == 40.0
+
+
+def test_single_process_is_a_noop():
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        os.environ.pop(k, None)
+    assert replicas.init("gloo") is None
+    assert replicas.max_over_ranks(3.5, None, torch.device("cpu")) == 3.5
+    assert replicas.shard_frames(5, 0, 1) == [0, 1, 2, 3, 4]
