@@ -78,6 +78,7 @@ SIGNATURES = {
     "bevf_cam_mean_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_bilinear_nhwc_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 8 + [C.c_void_p]),
     "bevf_broadcast_nhwc_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
+    "bevf_expand_border_classes_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 5 + [C.c_void_p]),
     "bevf_head_tail_f32": (C.c_int, [C.POINTER(HeadDesc), C.c_void_p]),
     "bevf_nchw_to_nhwc_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_nhwc_to_nchw_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
@@ -225,6 +226,13 @@ def broadcast_nhwc(v, y, B: int, P: int, Cc: int, y_cs: int):
     if v.numel() < B * Cc or y.numel() < (B * P - 1) * y_cs + Cc:
         raise BevfError("broadcast: buffer too small")
     _check(lib().bevf_broadcast_nhwc_f32(_p(v), _p(y), B, P, Cc, y_cs, _stream()), "bevf_broadcast_nhwc_f32")
+
+
+def expand_border_classes(small, y, B: int, Sh: int, Sw: int, Cc: int, y_cs: int):
+    if small.numel() < B * 25 * Cc or y.numel() < (B * Sh * Sw - 1) * y_cs + Cc:
+        raise BevfError("expand: buffer too small")
+    _check(lib().bevf_expand_border_classes_f32(_p(small), _p(y), B, Sh, Sw, Cc, y_cs, _stream()),
+           "bevf_expand_border_classes_f32")
 
 
 def head_tail(hid, w, bias, outs: Sequence[torch.Tensor], B: int, P: int, hc: int, cs: Sequence[int], n_sigmoid: int):

@@ -79,6 +79,28 @@ __global__ __launch_bounds__(256) void broadcast_nhwc(const float* __restrict__ 
   }
 }
 
+// A 3x3/pad-1 conv stack applied to a spatially CONSTANT image (the radar branch, ref src/fusion.py:277-281)
+// produces at most 5x5 distinct pixel values per channel after two layers: a pixel's value depends only on
+// which of its taps fall outside the image, i.e. on its border class {0, 1, interior, S-2, S-1} per axis.
+// The convs therefore run on a 5x5 image (identical FMA chains, bit-identical values) and this kernel
+// expands the 5x5 classes to the S_h x S_w map, written straight into the concat slice.
+__device__ __forceinline__ int border_class(int i, int S) { return i < 2 ? i : (i >= S - 2 ? 4 - (S - 1 - i) : 2); }
+
+__global__ __launch_bounds__(256) void expand_border_classes(const float* __restrict__ small, float* __restrict__ y,
+                                                              int Sh, int Sw, int C, int y_cs, long long total) {
+  const int c4 = C >> 2;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % c4) * 4;
+    const long long pix = i / c4;
+    const int w = (int)(pix % Sw);
+    const long long t = pix / Sw;
+    const int hh = (int)(t % Sh), b = (int)(t / Sh);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(
+        small + ((size_t)(b * 5 + border_class(hh, Sh)) * 5 + border_class(w, Sw)) * C + c);
+    *reinterpret_cast<f32x4*>(y + (size_t)pix * y_cs + c) = v;
+  }
+}
+
 // CenterNet head tail (ref src/fusion.py:869-884): per pixel, five 1x1 convs on the five
 // hc-wide slices of the hidden map, sigmoid on the first n_sigmoid outputs, NCHW stores.
 struct HeadArgs {
@@ -189,6 +211,18 @@ extern "C" int bevf_broadcast_nhwc_f32(const float* v, float* y, int B, int P, i
   hipLaunchKernelGGL(broadcast_nhwc, dim3(stream_grid(total)), dim3(256), 0, static_cast<hipStream_t>(stream), v, y, P,
                      C, y_cs, total);
   return bevf_check_launch("bevf_broadcast_nhwc_f32");
+}
+
+extern "C" int bevf_expand_border_classes_f32(const float* small, float* y, int B, int Sh, int Sw, int C, int y_cs,
+                                             void* stream) {
+  BEVF_REQUIRE(small && y, "expand: null pointer");
+  BEVF_REQUIRE(B > 0 && Sh >= 5 && Sw >= 5 && C > 0 && C % 4 == 0 && y_cs >= C && y_cs % 4 == 0,
+               "expand: needs S >= 5 and C %% 4 == 0 (Sh=%d Sw=%d C=%d)", Sh, Sw, C);
+  BEVF_REQUIRE(bevf_aligned16(small) && bevf_aligned16(y), "expand: unaligned");
+  const long long total = (long long)B * Sh * Sw * (C / 4);
+  hipLaunchKernelGGL(expand_border_classes, dim3(stream_grid(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     small, y, Sh, Sw, C, y_cs, total);
+  return bevf_check_launch("bevf_expand_border_classes_f32");
 }
 
 extern "C" int bevf_head_tail_f32(const bevf_head_desc* d, void* stream) {

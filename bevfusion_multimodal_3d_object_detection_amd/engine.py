@@ -329,6 +329,8 @@ class RadarEngine(_Engine):
 # ---- BEV fusion (ref src/fusion.py:209-297) ----------------------------------------------------------------
 
 class FusionEngine(_Engine):
+    collapse_radar = True        # set False to run radar_refine on the full map (tests compare both, bit for bit)
+
     def pack(self) -> None:
         m = self.module
         if m.use_camera:
@@ -412,11 +414,21 @@ class FusionEngine(_Engine):
         if "r" in present:
             rv = self.buf("rad_v", B * bc)
             L.linear(radar.contiguous(), self.rp[0], self.rp[1], rv, B, self.rp[0].shape[1], bc, True)
-            r0 = self.buf("rad_0", B * P * bc)
-            L.broadcast_nhwc(rv, r0, B, P, bc, bc)
-            r1 = self.buf("rad_1", B * P * bc)
-            _run_conv(self.rr1, r0, r1, B, Sh, Sw)
-            _run_conv(self.rr2, r1, concat[slot * bc:], B, Sh, Sw, y_cs=ccs)
+            if Sh >= 5 and Sw >= 5 and self.collapse_radar:
+                # exact shortcut: two 3x3/pad-1 convs on a constant image have 5x5 distinct pixels (bevpool.hip)
+                r0 = self.buf("rad_0", B * 25 * bc)
+                L.broadcast_nhwc(rv, r0, B, 25, bc, bc)
+                r1 = self.buf("rad_1", B * 25 * bc)
+                _run_conv(self.rr1, r0, r1, B, 5, 5)
+                r2 = self.buf("rad_2", B * 25 * bc)
+                _run_conv(self.rr2, r1, r2, B, 5, 5)
+                L.expand_border_classes(r2, concat[slot * bc:], B, Sh, Sw, bc, ccs)
+            else:
+                r0 = self.buf("rad_0", B * P * bc)
+                L.broadcast_nhwc(rv, r0, B, P, bc, bc)
+                r1 = self.buf("rad_1", B * P * bc)
+                _run_conv(self.rr1, r0, r1, B, Sh, Sw)
+                _run_conv(self.rr2, r1, concat[slot * bc:], B, Sh, Sw, y_cs=ccs)
             slot += 1
         f1 = self.buf("fus_1", B * P * self.f1.cout)
         _run_conv(self.f1, concat, f1, B, Sh, Sw)

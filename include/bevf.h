@@ -118,6 +118,13 @@ int bevf_bilinear_nhwc_f32(const float* x, float* y, int B, int Hi, int Wi, int 
 /* radar broadcast, ref src/fusion.py:277-278: y[b][p][0:C] = v[b][0:C] for p < P.            */
 int bevf_broadcast_nhwc_f32(const float* v, float* y, int B, int P, int C, int y_cs, void* stream);
 
+/* Radar branch shortcut (exact): a 3x3/pad-1 conv stack on a spatially constant image yields at most 5x5
+ * distinct pixels after two layers (a pixel's value depends only on its border class per axis), so
+ * radar_refine (ref src/fusion.py:189-196,281) runs on a 5x5 image and this expands the classes:
+ * y[b][i][j][0:C] = small[b][cls(i)][cls(j)][0:C], cls(i) = i<2 ? i : (i>=S-2 ? 4-(S-1-i) : 2).        */
+int bevf_expand_border_classes_f32(const float* small, float* y, int B, int Sh, int Sw, int C, int y_cs,
+                                   void* stream);
+
 /* CenterNet head tail: block-diagonal 1x1 convs of the five branches + sigmoid on the heatmap,
  * ref src/fusion.py:825,832,839,846,853,869-884.  hid: [B*P][5*hc] post-ReLU hidden maps;
  * w: concatenated [sum(c_k)][hc]; bias: [sum(c_k)]; outputs NCHW (B,c_k,H,W) as the reference

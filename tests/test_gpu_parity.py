@@ -301,3 +301,16 @@ def test_no_modality_raises(gpu):
     m = fusion.FlexibleBEVFusion(use_camera=True, use_lidar=False, use_radar=False, bev_h=8, bev_w=8).cuda().eval()
     with pytest.raises(ValueError, match="No modality features provided"):
         m(None, None, None)
+
+
+def test_radar_refine_collapse_is_bit_identical(gpu):
+    """The 5x5 border-class shortcut for the radar branch must reproduce the full-map convs bit for bit."""
+    for bev_h, bev_w in ((50, 50), (16, 24), (5, 7)):
+        m = fusion.FlexibleBEVFusion(use_camera=False, use_lidar=False, use_radar=True, bev_h=bev_h, bev_w=bev_w)
+        synth.fill_state_dict_(m, 31)
+        m = m.cuda().eval()
+        rad = synth.normal((3, 256), 32).cuda()
+        fast = m(None, None, rad).clone()
+        m._eng().collapse_radar = False
+        full = m(None, None, rad)
+        assert torch.equal(fast, full), (bev_h, bev_w)
