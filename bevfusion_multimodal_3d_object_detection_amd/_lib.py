@@ -55,6 +55,17 @@ class TargetsDesc(C.Structure):
                [("pc_range", C.c_float * 6), ("gaussian_overlap", C.c_float)]
 
 
+class WgradDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p), ("pixtab", C.c_void_p)] + \
+               [(n, C.c_int32) for n in ("N", "H", "W", "Cin", "x_cs", "Cout", "dy_cs", "KH", "KW", "stride", "pad")]
+
+
+class HeadBwdDesc(C.Structure):
+    _fields_ = [("hid", C.c_void_p), ("w", C.c_void_p), ("out0", C.c_void_p), ("dout", C.c_void_p * 5),
+                ("dhid", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("B", C.c_int32), ("P", C.c_int32),
+                ("hc", C.c_int32), ("c", C.c_int32 * 5), ("n_sigmoid", C.c_int32)]
+
+
 class LossDesc(C.Structure):
     _fields_ = [("pred_heatmap", C.c_void_p), ("tgt_heatmap", C.c_void_p), ("pred_reg", C.c_void_p * 4),
                 ("tgt_reg", C.c_void_p * 4), ("ind", C.c_void_p), ("reg_mask", C.c_void_p), ("work", C.c_void_p),
@@ -69,7 +80,7 @@ SIGNATURES = {
     "bevf_version": (C.c_int, []),
     "bevf_last_error": (C.c_char_p, []),
     "bevf_conv2d_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
-    "bevf_stem_conv7x7_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p]),
+    "bevf_stem_conv7x7_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_maxpool3x3s2_nhwc_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_pointwise_smallk_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_group_max_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 3 + [C.c_void_p]),
@@ -89,6 +100,30 @@ SIGNATURES = {
     "bevf_nms_keep_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 3 + [C.c_void_p]),
     "bevf_centernet_loss_work_floats": (C.c_size_t, []),
     "bevf_centernet_loss_f32": (C.c_int, [C.POINTER(LossDesc), C.c_void_p]),
+    # ---- training step ----
+    "bevf_conv_pixtab": (C.c_int, [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]),
+    "bevf_conv2d_wgrad_f32": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
+    "bevf_zero_stuff_nhwc_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 7 + [C.c_void_p]),
+    "bevf_bn_work_floats": (C.c_size_t, [C.c_int]),
+    "bevf_bn_stats_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_float, C.c_void_p]),
+    "bevf_bn_apply_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_void_p]),
+    "bevf_bn_backward_f32": (C.c_int, [C.c_void_p] * 10 + [C.c_int] * 4 + [C.c_void_p]),
+    "bevf_add_inplace_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "bevf_relu_mask_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "bevf_maxpool3x3s2_idx_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
+    "bevf_maxpool3x3s2_bwd_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
+    "bevf_bilinear_bwd_nhwc_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 8 + [C.c_void_p]),
+    "bevf_cam_mean_bwd_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
+    "bevf_group_max_idx_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
+    "bevf_group_max_bwd_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
+    "bevf_linear_bwd_work_floats": (C.c_size_t, [C.c_int] * 3),
+    "bevf_linear_bwd_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_void_p]),
+    "bevf_head_tail_bwd_f32": (C.c_int, [C.POINTER(HeadBwdDesc), C.c_void_p]),
+    "bevf_centernet_loss_bwd_f32": (C.c_int, [C.POINTER(LossDesc), C.c_void_p * 5, C.c_void_p, C.c_void_p]),
+    "bevf_stem_im2col_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 3 + [C.c_void_p]),
+    "bevf_smallk_wgrad_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
+    "bevf_grad_norm_f32": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "bevf_adamw_step_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_size_t] + [C.c_float] * 5 + [C.c_int, C.c_void_p]),
 }
 
 
@@ -158,11 +193,12 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, scale, shift, y: Optional[torc
     _check(lib().bevf_conv2d_nhwc_f32(C.byref(d), _stream()), "bevf_conv2d_nhwc_f32")
 
 
-def stem_conv7x7(x: torch.Tensor, w_packed: torch.Tensor, scale, shift, y: torch.Tensor, N: int, H: int, W: int):
+def stem_conv7x7(x: torch.Tensor, w_packed: torch.Tensor, scale, shift, y: torch.Tensor, N: int, H: int, W: int,
+                 relu: bool = True):
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     if x.numel() != N * 3 * H * W or w_packed.numel() != 148 * 64 or y.numel() < N * Ho * Wo * 64:
         raise BevfError("stem: buffer sizes do not match N,H,W")
-    _check(lib().bevf_stem_conv7x7_f32(_pc(x), _pc(w_packed), _pc(scale), _pc(shift), _p(y), N, H, W, _stream()),
+    _check(lib().bevf_stem_conv7x7_f32(_pc(x), _pc(w_packed), _pc(scale), _pc(shift), _p(y), N, H, W, int(relu), _stream()),
            "bevf_stem_conv7x7_f32")
 
 

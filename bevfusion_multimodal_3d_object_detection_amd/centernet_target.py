@@ -118,11 +118,14 @@ class CenterNetLoss(nn.Module):
         self.heatmap_weight, self.offset_weight = heatmap_weight, offset_weight
         self.size_weight, self.rot_weight, self.vel_weight = size_weight, rot_weight, vel_weight
 
-    @torch.no_grad()
     def forward(self, predictions: Dict[str, torch.Tensor], targets: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         E.require_cuda(predictions["heatmap"], targets["heatmap"])
         w = (self.heatmap_weight, self.offset_weight, self.size_weight, self.rot_weight, self.vel_weight)
-        vals = L.centernet_loss(predictions, targets, w)            # (6,) device tensor
+        if torch.is_grad_enabled() and any(t.requires_grad for t in predictions.values()):
+            from . import training
+            return training.loss_with_grad(predictions, targets, w)
+        with torch.no_grad():
+            vals = L.centernet_loss(predictions, targets, w)        # (6,) device tensor
         names = ("total_loss", "heatmap_loss", "offset_loss", "size_loss", "rot_loss", "vel_loss")
         return {n: vals[i] for i, n in enumerate(names)}
 

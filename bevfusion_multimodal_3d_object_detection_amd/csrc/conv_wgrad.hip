@@ -1,0 +1,234 @@
+// Weight gradient of the NHWC convolution on v_mfma_f32_32x32x2_f32 (training).
+//
+//   dW[co][tap][ci] = sum over output pixels m of  dY[m][co] * X[pixel(m) + tap][ci]
+//
+// GEMM view C[i = co][j = (tap,ci)] with the reduction running over pixels: both operands are stored
+// pixel-major (channel contiguous), so a 32-pixel step stages [32][BI] of dY and [32][BJ] of (shifted) X
+// in LDS and the MFMA fragments are plain ds_read_b32 with immediate offsets (lane = channel, the two
+// lane halves take the two pixels of a step).  The pixel range is split over workgroups (the output is
+// tiny, the reduction huge) and partial tiles are accumulated with fp32 atomics into a zeroed dW.
+// Pixel -> input-coordinate decoding comes from a per-shape table (no integer division in the loop).
+#include "common.h"
+
+#include <type_traits>
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+constexpr unsigned kOob = 0x80000000u;
+constexpr int PS = 32;   // pixels per step
+
+__device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+}
+
+// pixtab[m] = { n*H*W , (ih0 << 16) | (iw0 & 0xffff) } with ih0 = oh*stride - pad, iw0 = ow*stride - pad
+__global__ __launch_bounds__(256) void build_pixtab(i32x2* __restrict__ tab, int M, int H, int W, int Ho, int Wo,
+                                                     int stride, int pad) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  const int n = m / (Ho * Wo), r = m - n * Ho * Wo, oh = r / Wo, ow = r - oh * Wo;
+  const int ih0 = oh * stride - pad, iw0 = ow * stride - pad;
+  tab[m] = i32x2{n * H * W, (int)(((unsigned)ih0 << 16) | ((unsigned)iw0 & 0xffffu))};
+}
+
+struct WgradArgs {
+  const float* x;
+  const float* dy;
+  float* dw;
+  const i32x2* pixtab;
+  int H, W, Cin, x_cs, Cout, dy_cs, KW, M, K;
+  int tilesI, tilesJ, steps_per_split;
+};
+
+template <int BI, int BJ, int WI, int WJ>
+__global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradArgs p) {
+  constexpr int MI = WI / 32, NI = WJ / 32, WAVES_J = BJ / WJ;
+  static_assert((BI / WI) * (BJ / WJ) == 4, "4 waves");
+  constexpr int A_BYTES = PS * BI * 4, B_BYTES = PS * BJ * 4;
+  constexpr int ACH = BI / 4, BCH = BJ / 4;            // 16-B chunks per staged row
+  constexpr int AROWS = 256 / ACH, BROWS = 256 / BCH;  // rows covered per pass
+  constexpr int AP = PS / AROWS, BP = PS / BROWS;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* const ldsb = reinterpret_cast<char*>(lds);     // [A0][A1][B0][B1]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave / WAVES_J, wj = wave % WAVES_J;
+  const int split = blockIdx.x / (p.tilesI * p.tilesJ);
+  const int t = blockIdx.x - split * (p.tilesI * p.tilesJ);
+  const int i0 = (t / p.tilesJ) * BI, j0 = (t % p.tilesJ) * BJ;
+  const int step0 = split * p.steps_per_split;
+  int nsteps = (p.M + PS - 1) / PS - step0;
+  if (nsteps > p.steps_per_split) nsteps = p.steps_per_split;
+  if (nsteps <= 0) return;
+
+  // ---- staging roles ---------------------------------------------------------------------------------------
+  const int a_chunk = tid % ACH, a_row = tid / ACH;
+  const int b_chunk = tid % BCH, b_row = tid / BCH;
+  const bool a_ok = i0 + a_chunk * 4 < p.Cout;
+  const int jj = j0 + b_chunk * 4;                     // this thread's column of C: fixed (tap, ci)
+  const bool b_ok = jj < p.K;
+  const int tap = b_ok ? jj / p.Cin : 0, ci = b_ok ? jj - tap * p.Cin : 0;
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  // dY rows past M read as zero through the descriptor's bound; x rows are predicated per pixel
+  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.dy), 0, (int)(((size_t)(p.M - 1) * p.dy_cs + p.Cout) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)kOob, 0x00020000);
+  unsigned a_voff[AP];                                 // byte offset of this thread's rows in step 0 of the split
+#pragma unroll
+  for (int q = 0; q < AP; ++q)
+    a_voff[q] = (unsigned)((((size_t)(step0 * PS + a_row + q * AROWS)) * p.dy_cs + i0 + a_chunk * 4) * 4);
+  const unsigned a_step = (unsigned)(PS * p.dy_cs * 4);
+
+  f32x4 ra[AP], rb[BP];
+  i32x2 tabv[BP];
+  auto load_tab = [&](int step) {
+#pragma unroll
+    for (int q = 0; q < BP; ++q) {
+      int m = (step0 + step) * PS + b_row + q * BROWS;
+      m = m < p.M ? m : p.M - 1;                      // rows past M multiply a zero dY row
+      tabv[q] = p.pixtab[m];
+    }
+  };
+  auto load_tiles = [&](int step) {
+#pragma unroll
+    for (int q = 0; q < AP; ++q)   // the whole offset goes in voffset so the descriptor's bound zero-fills rows >= M
+      ra[q] = buf_load16(rsrcA, a_ok ? a_voff[q] + (unsigned)step * a_step : kOob, 0);
+#pragma unroll
+    for (int q = 0; q < BP; ++q) {
+      const int ih = (tabv[q].y >> 16) + kh, iw = (int)(short)(tabv[q].y & 0xffff) + kw;
+      const bool ok = b_ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      const unsigned voff = ok ? (unsigned)(((tabv[q].x + ih * p.W + iw) * p.x_cs + ci) * 4) : kOob;
+      rb[q] = buf_load16(rsrcB, voff, 0);
+    }
+  };
+  const int a_wr = (a_row * BI + a_chunk * 4) * 4, b_wr = 2 * A_BYTES + (b_row * BJ + b_chunk * 4) * 4;
+  auto store_tiles = [&](auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+    for (int q = 0; q < AP; ++q) *reinterpret_cast<f32x4*>(ldsb + a_wr + buf * A_BYTES + q * AROWS * BI * 4) = ra[q];
+#pragma unroll
+    for (int q = 0; q < BP; ++q) *reinterpret_cast<f32x4*>(ldsb + b_wr + buf * B_BYTES + q * BROWS * BJ * 4) = rb[q];
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int h = lane >> 5, l31 = lane & 31;
+  const int a_rd = (h * BI + wi * WI + l31) * 4, b_rd = 2 * A_BYTES + (h * BJ + wj * WJ + l31) * 4;
+  auto compute = [&](auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+    for (int s = 0; s < PS / 2; ++s) {
+      float a[MI], b[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        a[mi] = *reinterpret_cast<const float*>(ldsb + a_rd + buf * A_BYTES + s * 2 * BI * 4 + mi * 128);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        b[ni] = *reinterpret_cast<const float*>(ldsb + b_rd + buf * B_BYTES + s * 2 * BJ * 4 + ni * 128);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    }
+  };
+
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  load_tab(0);
+  load_tiles(0);
+  if (nsteps > 1) load_tab(1);
+  store_tiles(B0{});
+  __syncthreads();
+  int s = 0;
+  for (; s + 2 <= nsteps; s += 2) {
+    load_tiles(s + 1);
+    if (s + 2 < nsteps) load_tab(s + 2);
+    compute(B0{});
+    store_tiles(B1{});
+    __syncthreads();
+    const bool more = s + 2 < nsteps;
+    if (more) {
+      load_tiles(s + 2);
+      if (s + 3 < nsteps) load_tab(s + 3);
+    }
+    compute(B1{});
+    if (more) store_tiles(B0{});
+    __syncthreads();
+  }
+  if (s < nsteps) {
+    compute(B0{});
+    __syncthreads();
+  }
+
+  // ---- accumulate the partial tile: rows i = co, columns j = (tap,ci); 32 lanes = 128 contiguous bytes ----
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int j = j0 + wj * WJ + ni * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = i0 + wi * WI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (co < p.Cout && j < p.K) atomicAdd(&p.dw[(size_t)co * p.K + j], acc[mi][ni][r]);
+      }
+    }
+}
+
+template <int BI, int BJ, int WI, int WJ>
+int launch_wgrad(WgradArgs a, hipStream_t st) {
+  a.tilesI = (a.Cout + BI - 1) / BI;
+  a.tilesJ = (a.K + BJ - 1) / BJ;
+  const int steps = (a.M + PS - 1) / PS;
+  int splits = 1024 / (a.tilesI * a.tilesJ);            // ~4 workgroups per CU in flight
+  if (splits < 1) splits = 1;
+  if (splits > steps) splits = steps;
+  a.steps_per_split = (steps + splits - 1) / splits;
+  splits = (steps + a.steps_per_split - 1) / a.steps_per_split;
+  constexpr size_t lds_bytes = size_t(2) * PS * (BI + BJ) * sizeof(float);
+  hipLaunchKernelGGL((conv_wgrad_f32<BI, BJ, WI, WJ>), dim3(a.tilesI * a.tilesJ * splits), dim3(256), lds_bytes, st, a);
+  return bevf_check_launch("bevf_conv2d_wgrad_f32");
+}
+
+}  // namespace
+
+extern "C" int bevf_conv_pixtab(int32_t* tab, int N, int H, int W, int KH, int KW, int stride, int pad, void* stream) {
+  BEVF_REQUIRE(tab && N > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, "pixtab: bad arguments");
+  BEVF_REQUIRE(H < 32768 && W < 32768, "pixtab: H/W must fit 15 bits");
+  const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  const long long M = (long long)N * Ho * Wo;
+  BEVF_REQUIRE(M > 0 && M < (1ll << 31), "pixtab: bad pixel count");
+  hipLaunchKernelGGL(build_pixtab, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<i32x2*>(tab), (int)M, H, W, Ho, Wo, stride, pad);
+  return bevf_check_launch("bevf_conv_pixtab");
+}
+
+extern "C" int bevf_conv2d_wgrad_f32(const bevf_wgrad_desc* d, void* stream) {
+  BEVF_REQUIRE(d && d->x && d->dy && d->dw && d->pixtab, "wgrad: null pointer");
+  BEVF_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cout > 0 && d->Cin > 0 && d->Cin % 4 == 0,
+               "wgrad: Cin=%d must be a positive multiple of 4", d->Cin);
+  BEVF_REQUIRE(d->x_cs >= d->Cin && d->x_cs % 4 == 0 && d->dy_cs >= d->Cout && d->dy_cs % 4 == 0 && d->Cout % 4 == 0,
+               "wgrad: channel strides / Cout must be multiples of 4");
+  BEVF_REQUIRE(bevf_aligned16(d->x) && bevf_aligned16(d->dy), "wgrad: unaligned");
+  const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+  const long long M = (long long)d->N * Ho * Wo;
+  BEVF_REQUIRE(M > 0 && M < (1ll << 31), "wgrad: bad pixel count");
+  BEVF_REQUIRE((long long)d->N * d->H * d->W * d->x_cs * 4 < (1ll << 31) && M * d->dy_cs * 4 < (1ll << 31),
+               "wgrad: x / dy buffers must stay below 2 GiB (32-bit buffer offsets)");
+  WgradArgs a;
+  a.x = d->x; a.dy = d->dy; a.dw = d->dw; a.pixtab = reinterpret_cast<const i32x2*>(d->pixtab);
+  a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.x_cs = d->x_cs; a.Cout = d->Cout; a.dy_cs = d->dy_cs; a.KW = d->KW;
+  a.M = (int)M; a.K = d->KH * d->KW * d->Cin;
+  a.tilesI = a.tilesJ = a.steps_per_split = 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (d->Cout <= 64) return launch_wgrad<64, 128, 64, 32>(a, st);
+  return launch_wgrad<128, 128, 64, 64>(a, st);
+}

@@ -1,0 +1,258 @@
+// Train-mode BatchNorm on NHWC rows ([M][C], channel stride cs): batch statistics, apply (+residual, +ReLU),
+// and the backward pair (per-channel reductions, then the element-wise input gradient).
+//   forward : torch.nn.BatchNorm{1,2}d in training mode, as every conv/bn pair of ref src/encoders.py and
+//             src/fusion.py runs under model.train() (ref src/train_detect.py:395-434)
+// Reductions are two-stage and order-fixed (deterministic): fp32 partial sums per workgroup, merged in
+// double.  Variance uses sums shifted by the first row (no catastrophic cancellation when |mean| >> std).
+#include "common.h"
+
+namespace {
+
+constexpr int kStatGrid = 256;
+
+// thread (cq, rl): channel quad cq = tid % C4, row lane rl = tid / C4; C4 = C/4 <= 256 and a power of two * ...
+struct RowMap {
+  int c4, lanes;
+  __device__ RowMap(int C) : c4(C >> 2), lanes(256 / (C >> 2) > 0 ? 256 / (C >> 2) : 1) {}
+};
+
+// partial[g][c] = {sum(x-s), sum((x-s)^2)} ; shift s[c] = x[0][c]
+__global__ __launch_bounds__(256) void stats_partials(const float* __restrict__ x, float* __restrict__ part, int M, int C,
+                                                       int cs) {
+  extern __shared__ float red[];                      // [256][8]
+  const int c4 = C >> 2;
+  const int lanes = c4 >= 256 ? 1 : 256 / c4;
+  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  for (int cq = threadIdx.x % (c4 < 256 ? c4 : 256); cq < c4; cq += 256) {   // C > 1024: loop over quads
+    const int rl = c4 >= 256 ? 0 : threadIdx.x / c4;
+    if (rl >= lanes) break;
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(x + cq * 4);
+    float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+    for (long long m = (long long)blockIdx.x * lanes + rl; m < M; m += (long long)gridDim.x * lanes) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)m * cs + cq * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float d = v[j] - sh[j]; a1[j] += d; a2[j] = fmaf(d, d, a2[j]); }
+    }
+    if (c4 >= 256) {                                  // one row lane: write directly
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        part[((size_t)blockIdx.x * C + cq * 4 + j) * 2] = a1[j];
+        part[((size_t)blockIdx.x * C + cq * 4 + j) * 2 + 1] = a2[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s1[j] = a1[j]; s2[j] = a2[j]; }
+    }
+  }
+  if (c4 < 256) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[threadIdx.x * 8 + j] = s1[j]; red[threadIdx.x * 8 + 4 + j] = s2[j]; }
+    __syncthreads();
+    if ((int)threadIdx.x < c4) {                      // fixed-order merge over the row lanes
+      float t1[4] = {0, 0, 0, 0}, t2[4] = {0, 0, 0, 0};
+      for (int rl = 0; rl < lanes; ++rl)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          t1[j] += red[(rl * c4 + threadIdx.x) * 8 + j];
+          t2[j] += red[(rl * c4 + threadIdx.x) * 8 + 4 + j];
+        }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        part[((size_t)blockIdx.x * C + threadIdx.x * 4 + j) * 2] = t1[j];
+        part[((size_t)blockIdx.x * C + threadIdx.x * 4 + j) * 2 + 1] = t2[j];
+      }
+    }
+  }
+}
+
+// mean, biased var, invstd from the partials (double, fixed order)
+__global__ __launch_bounds__(256) void stats_finalize(const float* __restrict__ x, const float* __restrict__ part,
+                                                       float* __restrict__ mean, float* __restrict__ var,
+                                                       float* __restrict__ invstd, int M, int C, int G, float eps) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0, s2 = 0;
+  for (int g = 0; g < G; ++g) { s1 += part[((size_t)g * C + c) * 2]; s2 += part[((size_t)g * C + c) * 2 + 1]; }
+  const double sh = x[c], d = s1 / M;
+  const double v = s2 / M - d * d;
+  mean[c] = (float)(sh + d);
+  var[c] = (float)(v > 0 ? v : 0);
+  invstd[c] = (float)(1.0 / sqrt((v > 0 ? v : 0) + (double)eps));
+}
+
+// y = act((x - mean) * invstd * gamma + beta (+ res))
+__global__ __launch_bounds__(256) void bn_apply(const float* __restrict__ x, const float* __restrict__ mean,
+                                                 const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, const float* __restrict__ res,
+                                                 float* __restrict__ y, long long M, int C, int cs, int relu) {
+  const int c4 = C >> 2;
+  const long long total = M * c4;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % c4) * 4;
+    const long long m = i / c4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)m * cs + c);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = (gamma ? gamma[c + j] : 1.f) * invstd[c + j];
+      const float b = (beta ? beta[c + j] : 0.f) - mean[c + j] * a;
+      float t = fmaf(v[j], a, b);
+      if (res) t += res[(size_t)m * C + c + j];
+      o[j] = relu ? fmaxf(t, 0.f) : t;
+    }
+    *reinterpret_cast<f32x4*>(y + (size_t)m * C + c) = o;
+  }
+}
+
+// backward stage 1: dy <- dy * (y > 0) when relu; partial[g][c] = {sum dy, sum dy*xhat}
+__global__ __launch_bounds__(256) void bn_bwd_partials(float* __restrict__ dy, const float* __restrict__ y,
+                                                        const float* __restrict__ x, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, float* __restrict__ part,
+                                                        int M, int C, int cs, int relu) {
+  extern __shared__ float red[];
+  const int c4 = C >> 2;
+  const int lanes = c4 >= 256 ? 1 : 256 / c4;
+  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  for (int cq = threadIdx.x % (c4 < 256 ? c4 : 256); cq < c4; cq += 256) {
+    const int rl = c4 >= 256 ? 0 : threadIdx.x / c4;
+    if (rl >= lanes) break;
+    float mu[4], is[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { mu[j] = mean ? mean[cq * 4 + j] : 0.f; is[j] = invstd ? invstd[cq * 4 + j] : 1.f; }
+    float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+    for (long long m = (long long)blockIdx.x * lanes + rl; m < M; m += (long long)gridDim.x * lanes) {
+      f32x4 g = *reinterpret_cast<const f32x4*>(dy + (size_t)m * C + cq * 4);
+      if (relu) {
+        const f32x4 yy = *reinterpret_cast<const f32x4*>(y + (size_t)m * C + cq * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = yy[j] > 0.f ? g[j] : 0.f;
+        *reinterpret_cast<f32x4*>(dy + (size_t)m * C + cq * 4) = g;
+      }
+      if (x) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)m * cs + cq * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a1[j] += g[j]; a2[j] = fmaf(g[j], (xv[j] - mu[j]) * is[j], a2[j]); }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a1[j] += g[j];
+      }
+    }
+    if (c4 >= 256) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        part[((size_t)blockIdx.x * C + cq * 4 + j) * 2] = a1[j];
+        part[((size_t)blockIdx.x * C + cq * 4 + j) * 2 + 1] = a2[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s1[j] = a1[j]; s2[j] = a2[j]; }
+    }
+  }
+  if (c4 < 256) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[threadIdx.x * 8 + j] = s1[j]; red[threadIdx.x * 8 + 4 + j] = s2[j]; }
+    __syncthreads();
+    if ((int)threadIdx.x < c4) {
+      float t1[4] = {0, 0, 0, 0}, t2[4] = {0, 0, 0, 0};
+      for (int rl = 0; rl < lanes; ++rl)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          t1[j] += red[(rl * c4 + threadIdx.x) * 8 + j];
+          t2[j] += red[(rl * c4 + threadIdx.x) * 8 + 4 + j];
+        }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        part[((size_t)blockIdx.x * C + threadIdx.x * 4 + j) * 2] = t1[j];
+        part[((size_t)blockIdx.x * C + threadIdx.x * 4 + j) * 2 + 1] = t2[j];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sums_finalize(const float* __restrict__ part, float* __restrict__ s_dy,
+                                                      float* __restrict__ s_dyx, int C, int G) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0, s2 = 0;
+  for (int g = 0; g < G; ++g) { s1 += part[((size_t)g * C + c) * 2]; s2 += part[((size_t)g * C + c) * 2 + 1]; }
+  s_dy[c] = (float)s1;
+  if (s_dyx) s_dyx[c] = (float)s2;
+}
+
+// backward stage 2: dx = gamma*invstd * (dy - sum_dy/M - xhat * sum_dyx/M)
+__global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                     const float* __restrict__ gamma, const float* __restrict__ s_dy,
+                                                     const float* __restrict__ s_dyx, float* __restrict__ dx,
+                                                     long long M, int C, int cs) {
+  const int c4 = C >> 2;
+  const long long total = M * c4;
+  const float invM = 1.f / (float)M;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % c4) * 4;
+    const long long m = i / c4;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dy + (size_t)m * C + c);
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)m * cs + c);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float is = invstd[c + j], xh = (xv[j] - mean[c + j]) * is;
+      o[j] = (gamma ? gamma[c + j] : 1.f) * is * (g[j] - s_dy[c + j] * invM - xh * s_dyx[c + j] * invM);
+    }
+    *reinterpret_cast<f32x4*>(dx + (size_t)m * cs + c) = o;
+  }
+}
+
+static inline unsigned ew_grid(long long items) {
+  long long g = (items + 255) / 256;
+  return (unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" size_t bevf_bn_work_floats(int C) { return (size_t)kStatGrid * C * 2; }
+
+extern "C" int bevf_bn_stats_f32(const float* x, float* work, float* mean, float* var, float* invstd, int M, int C,
+                                 int cs, float eps, void* stream) {
+  BEVF_REQUIRE(x && work && mean && var && invstd, "bn_stats: null pointer");
+  BEVF_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && cs >= C && cs % 4 == 0, "bn_stats: bad shape (M=%d C=%d cs=%d)", M, C, cs);
+  BEVF_REQUIRE(bevf_aligned16(x), "bn_stats: unaligned");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int lanes = C / 4 >= 256 ? 1 : 256 / (C / 4);
+  int G = (M + lanes - 1) / lanes;
+  if (G > kStatGrid) G = kStatGrid;
+  hipLaunchKernelGGL(stats_partials, dim3(G), dim3(256), 256 * 8 * sizeof(float), st, x, work, M, C, cs);
+  hipLaunchKernelGGL(stats_finalize, dim3((C + 255) / 256), dim3(256), 0, st, x, work, mean, var, invstd, M, C, G, eps);
+  return bevf_check_launch("bevf_bn_stats_f32");
+}
+
+extern "C" int bevf_bn_apply_f32(const float* x, const float* mean, const float* invstd, const float* gamma,
+                                 const float* beta, const float* res, float* y, int M, int C, int cs, int relu,
+                                 void* stream) {
+  BEVF_REQUIRE(x && mean && invstd && y, "bn_apply: null pointer");
+  BEVF_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && cs >= C && cs % 4 == 0, "bn_apply: bad shape");
+  BEVF_REQUIRE(bevf_aligned16(x) && bevf_aligned16(y) && (!res || bevf_aligned16(res)), "bn_apply: unaligned");
+  hipLaunchKernelGGL(bn_apply, dim3(ew_grid((long long)M * (C / 4))), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     mean, invstd, gamma, beta, res, y, (long long)M, C, cs, relu);
+  return bevf_check_launch("bevf_bn_apply_f32");
+}
+
+extern "C" int bevf_bn_backward_f32(float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                                    const float* gamma, float* work, float* dgamma, float* dbeta, float* dx, int M,
+                                    int C, int cs, int relu, void* stream) {
+  BEVF_REQUIRE(dy && work && dbeta, "bn_backward: null pointer");
+  BEVF_REQUIRE(!relu || y, "bn_backward: relu needs the forward output");
+  BEVF_REQUIRE(!dx || (x && mean && invstd && dgamma), "bn_backward: dx needs x, mean, invstd, dgamma");
+  BEVF_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && cs >= C && cs % 4 == 0, "bn_backward: bad shape");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int lanes = C / 4 >= 256 ? 1 : 256 / (C / 4);
+  int G = (M + lanes - 1) / lanes;
+  if (G > kStatGrid) G = kStatGrid;
+  hipLaunchKernelGGL(bn_bwd_partials, dim3(G), dim3(256), 256 * 8 * sizeof(float), st, dy, y, x, mean, invstd, work, M, C,
+                     cs, relu);
+  hipLaunchKernelGGL(sums_finalize, dim3((C + 255) / 256), dim3(256), 0, st, work, dbeta, dgamma, C, G);
+  if (dx)
+    hipLaunchKernelGGL(bn_bwd_apply, dim3(ew_grid((long long)M * (C / 4))), dim3(256), 0, st, dy, x, mean, invstd, gamma,
+                       dbeta, dgamma, dx, (long long)M, C, cs);
+  return bevf_check_launch("bevf_bn_backward_f32");
+}

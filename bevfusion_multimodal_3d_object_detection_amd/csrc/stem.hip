@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void stem_conv7x7_f32(const float* __restrict_
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift, float* __restrict__ y,
                                                          int H, int W, int Ho, int Wo, int tilesW, int tilesH,
-                                                         int vec_ok) {
+                                                         int vec_ok, int relu) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* wl = smem;                      // [KPAD][64]
   float* patch = smem + KPAD * 64;       // [3][PR][PW]
@@ -136,8 +136,8 @@ __global__ __launch_bounds__(256) void stem_conv7x7_f32(const float* __restrict_
       const int i = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       if (ow0 + i < Wo) {
         const float v0 = fmaf(acc0[r], sc0, sh0), v1 = fmaf(acc1[r], sc1, sh1);
-        yrow[(size_t)i * 64 + l31] = v0 > 0.f ? v0 : 0.f;
-        yrow[(size_t)i * 64 + l31 + 32] = v1 > 0.f ? v1 : 0.f;
+        yrow[(size_t)i * 64 + l31] = relu ? fmaxf(v0, 0.f) : v0;
+        yrow[(size_t)i * 64 + l31 + 32] = relu ? fmaxf(v1, 0.f) : v1;
       }
     }
   }
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc(const float* __restrict
 }  // namespace
 
 extern "C" int bevf_stem_conv7x7_f32(const float* x, const float* w, const float* scale, const float* shift,
-                                     float* y, int N, int H, int W, void* stream) {
+                                     float* y, int N, int H, int W, int relu, void* stream) {
   BEVF_REQUIRE(x && w && scale && shift && y, "stem: null pointer");
   BEVF_REQUIRE(bevf_aligned16(w), "stem: packed filter bank must be 16-byte aligned");
   BEVF_REQUIRE(N > 0 && H >= 1 && W >= 1, "stem: empty shape");
@@ -191,7 +191,7 @@ extern "C" int bevf_stem_conv7x7_f32(const float* x, const float* w, const float
     attr_done = true;
   }
   hipLaunchKernelGGL(stem_conv7x7_f32, dim3((unsigned)grid), dim3(256), kStemLds, static_cast<hipStream_t>(stream), x,
-                     w, scale, shift, y, H, W, Ho, Wo, tilesW, tilesH, (W % 4 == 0 && bevf_aligned16(x)) ? 1 : 0);
+                     w, scale, shift, y, H, W, Ho, Wo, tilesW, tilesH, (W % 4 == 0 && bevf_aligned16(x)) ? 1 : 0, relu);
   return bevf_check_launch("bevf_stem_conv7x7_f32");
 }
 

@@ -266,9 +266,16 @@ class FlexibleMultiModal3DDetector(nn.Module):
         else:
             self.det_head = MLPDetectionHead()
 
-    @torch.no_grad()
     def forward(self, camera_imgs: Optional[torch.Tensor] = None, lidar_points: Optional[torch.Tensor] = None,
                 radar_points: Optional[List[torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        if self.training and torch.is_grad_enabled():
+            from . import training                      # train-mode BN + tape + hand-written backward (training.py)
+            E.require_cuda(camera_imgs, lidar_points)
+            return training.detector_train_forward(self, camera_imgs, lidar_points, radar_points)
+        with torch.no_grad():
+            return self._forward_inference(camera_imgs, lidar_points, radar_points)
+
+    def _forward_inference(self, camera_imgs, lidar_points, radar_points) -> Dict[str, torch.Tensor]:
         cam = geom = lid = rad = None
         if self.use_camera and camera_imgs is not None:
             cam, geom = self.camera_encoder.forward_nhwc(camera_imgs)       # stays NHWC: no layout change

@@ -1,0 +1,672 @@
+"""Training step on the HIP path (ref src/train_detect.py:401-434).
+
+`model.train()` routes `FlexibleMultiModal3DDetector.forward` through `_DetectorTrainFn`, one
+`torch.autograd.Function` for the whole detector: the forward runs the same NHWC kernels as inference but
+with train-mode BatchNorm (batch statistics, running-stat update) and keeps a tape; the backward walks the
+tape with hand-written gradient kernels (MFMA weight / data gradients, BN, pooling, resample, dense layers,
+head) and returns the parameter gradients to autograd, so the reference's training loop --
+`loss.backward(); clip_grad_norm_(...); optimizer.step()` -- works unchanged.  torch is used for tensor
+allocation and for weight layout permutes; no torch compute op touches an activation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import engine as E
+
+
+def _lib():
+    return L.lib()
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ck(rc, what):
+    if rc != 0:
+        raise L.BevfError(f"{what} failed ({rc}): {_lib().bevf_last_error().decode()}")
+
+
+def _new(n: int, dev, dtype=torch.float32) -> torch.Tensor:
+    return torch.empty(max(int(n), 4), dtype=dtype, device=dev)
+
+
+def _zeros(n: int, dev, dtype=torch.float32) -> torch.Tensor:
+    return torch.zeros(max(int(n), 4), dtype=dtype, device=dev)
+
+
+_PIXTAB: Dict[tuple, torch.Tensor] = {}
+
+
+def _pixtab(N, H, W, k, stride, pad, dev) -> torch.Tensor:
+    key = (N, H, W, k, stride, pad, str(dev))
+    t = _PIXTAB.get(key)
+    if t is None:
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        t = torch.empty(N * Ho * Wo * 2, dtype=torch.int32, device=dev)
+        _ck(_lib().bevf_conv_pixtab(t.data_ptr(), N, H, W, k, k, stride, pad, _st()), "bevf_conv_pixtab")
+        _PIXTAB[key] = t
+    return t
+
+
+# ---- primitive ops (thin wrappers over the C-ABI; all tensors fp32 cuda, flat NHWC) ---------------------------------
+
+def conv_raw(x, w_ohwi, bias, N, H, W, cin, cout, k, stride, pad, relu=False):
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    y = _new(N * Ho * Wo * cout, x.device)
+    L.conv2d_nhwc(x, w_ohwi, None, bias, y, N=N, H=H, W=W, Cin=cin, x_cs=cin, Cout=cout, y_cs=cout, KH=k, KW=k,
+                  stride=stride, pad=pad, relu=relu)
+    return y, Ho, Wo
+
+
+def conv_wgrad(x, dy, N, H, W, cin, cout, k, stride, pad, dw=None) -> torch.Tensor:
+    """Returns dW in OHWI layout [cout][k][k][cin] (accumulates into `dw` when given)."""
+    if dw is None:
+        dw = _zeros(cout * k * k * cin, x.device)
+    d = L.WgradDesc(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _pixtab(N, H, W, k, stride, pad, x.device).data_ptr(),
+                    N, H, W, cin, cin, cout, cout, k, k, stride, pad)
+    _ck(_lib().bevf_conv2d_wgrad_f32(C.byref(d), _st()), "bevf_conv2d_wgrad_f32")
+    return dw[:cout * k * k * cin].view(cout, k, k, cin)
+
+
+def conv_dgrad(dy, weight_oihw, N, H, W, cin, cout, k, stride, pad):
+    """dX [N*H*W*cin] = conv_transpose(dy, W): the forward kernel on (zero-stuffed) dy with the flipped filter."""
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    wt = weight_oihw.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous().view(-1)        # [cin][k][k][cout]
+    src, sh, sw = dy, Ho, Wo
+    if stride != 1:
+        src = _new(N * H * W * cout, dy.device)
+        _ck(_lib().bevf_zero_stuff_nhwc_f32(dy.data_ptr(), src.data_ptr(), N, Ho, Wo, cout, H, W, stride, _st()),
+            "bevf_zero_stuff_nhwc_f32")
+        sh, sw = H, W
+    else:
+        assert (Ho, Wo) == (H, W), "stride-1 convs on this path keep the spatial size"
+    dx = _new(N * H * W * cin, dy.device)
+    L.conv2d_nhwc(src, wt, None, None, dx, N=N, H=sh, W=sw, Cin=cout, x_cs=cout, Cout=cin, y_cs=cin, KH=k, KW=k,
+                  stride=1, pad=k - 1 - pad, relu=False)
+    return dx
+
+
+class _BNState:
+    __slots__ = ("mean", "invstd", "xraw", "y", "M", "C")
+
+
+def bn_train_forward(xraw, bn: nn.BatchNorm2d, M: int, Cc: int, res=None, relu=True):
+    dev = xraw.device
+    work = _new(_lib().bevf_bn_work_floats(Cc), dev)
+    mean, var, invstd = _new(Cc, dev), _new(Cc, dev), _new(Cc, dev)
+    _ck(_lib().bevf_bn_stats_f32(xraw.data_ptr(), work.data_ptr(), mean.data_ptr(), var.data_ptr(), invstd.data_ptr(),
+                                 M, Cc, Cc, float(bn.eps), _st()), "bevf_bn_stats_f32")
+    y = _new(M * Cc, dev)
+    g = bn.weight.data_ptr() if bn.weight is not None else None
+    b = bn.bias.data_ptr() if bn.bias is not None else None
+    _ck(_lib().bevf_bn_apply_f32(xraw.data_ptr(), mean.data_ptr(), invstd.data_ptr(), g, b,
+                                 res.data_ptr() if res is not None else None, y.data_ptr(), M, Cc, Cc, int(relu), _st()),
+        "bevf_bn_apply_f32")
+    if bn.track_running_stats and bn.running_mean is not None:           # torch: momentum 0.1, unbiased running var
+        with torch.no_grad():
+            mom = 0.1 if bn.momentum is None else bn.momentum
+            bn.running_mean.mul_(1 - mom).add_(mean[:Cc], alpha=mom)
+            bn.running_var.mul_(1 - mom).add_(var[:Cc], alpha=mom * M / max(M - 1, 1))
+            bn.num_batches_tracked.add_(1)
+    s = _BNState()
+    s.mean, s.invstd, s.xraw, s.y, s.M, s.C = mean, invstd, xraw, y, M, Cc
+    return y, s
+
+
+def bn_train_backward(dy, s: _BNState, bn, relu=True, need_dx=True):
+    """In place: dy <- dy*(y>0).  Returns (dxraw or None, dgamma, dbeta)."""
+    dev = dy.device
+    work = _new(_lib().bevf_bn_work_floats(s.C), dev)
+    dgamma, dbeta = _new(s.C, dev), _new(s.C, dev)
+    dx = _new(s.M * s.C, dev) if need_dx else None
+    g = bn.weight.data_ptr() if bn.weight is not None else None
+    _ck(_lib().bevf_bn_backward_f32(dy.data_ptr(), s.y.data_ptr(), s.xraw.data_ptr(), s.mean.data_ptr(),
+                                    s.invstd.data_ptr(), g, work.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                    dx.data_ptr() if dx is not None else None, s.M, s.C, s.C, int(relu), _st()),
+        "bevf_bn_backward_f32")
+    return dx, dgamma[:s.C], dbeta[:s.C]
+
+
+def colsum(dy, M, Cc):
+    """sum over rows (bias gradients)."""
+    work = _new(_lib().bevf_bn_work_floats(Cc), dy.device)
+    out = _new(Cc, dy.device)
+    _ck(_lib().bevf_bn_backward_f32(dy.data_ptr(), None, None, None, None, None, work.data_ptr(), None, out.data_ptr(),
+                                    None, M, Cc, Cc, 0, _st()), "bevf_bn_backward_f32(colsum)")
+    return out[:Cc]
+
+
+def add_(y, x, n):
+    n4 = (n + 3) // 4 * 4
+    _ck(_lib().bevf_add_inplace_f32(y.data_ptr(), x.data_ptr(), n4, _st()), "bevf_add_inplace_f32")
+
+
+class GradSink:
+    """Collects parameter gradients by parameter identity (summing repeated contributions)."""
+
+    def __init__(self):
+        self.g: Dict[int, torch.Tensor] = {}
+
+    def add(self, p: Optional[torch.Tensor], g: torch.Tensor):
+        if p is None or not p.requires_grad:
+            return
+        g = g.reshape(p.shape)
+        k = id(p)
+        self.g[k] = g if k not in self.g else self.g[k] + g
+
+    def get(self, p):
+        return self.g.get(id(p))
+
+
+# ---- layer records --------------------------------------------------------------------------------------------------------
+
+class ConvBNLayer:
+    """conv (any bias) -> train-mode BN -> (+residual) -> (ReLU).  bn None: conv(+bias)(+ReLU) only (head)."""
+
+    def __init__(self, conv, bn, relu=True):
+        self.conv, self.bn, self.relu = conv, bn, relu
+        w = conv.weight
+        self.k = w.shape[2] if w.dim() == 4 else 1
+        self.cin, self.cout = w.shape[1], w.shape[0]
+        self.stride = conv.stride[0]
+        self.pad = conv.padding[0]
+
+    def forward(self, x, N, H, W, res=None):
+        w4 = self.conv.weight.detach()
+        if w4.dim() == 3:
+            w4 = w4.unsqueeze(-1)
+        w_ohwi = w4.permute(0, 2, 3, 1).contiguous().view(-1)
+        bias = self.conv.bias.detach() if self.conv.bias is not None else None
+        self.x, self.N, self.H, self.W = x, N, H, W
+        if self.bn is None:
+            y, Ho, Wo = conv_raw(x, w_ohwi, bias, N, H, W, self.cin, self.cout, self.k, self.stride, self.pad, relu=self.relu)
+            self.y, self.M = y, N * Ho * Wo
+            return y, Ho, Wo
+        xraw, Ho, Wo = conv_raw(x, w_ohwi, bias, N, H, W, self.cin, self.cout, self.k, self.stride, self.pad)
+        self.M = N * Ho * Wo
+        y, self.bns = bn_train_forward(xraw, self.bn, self.M, self.cout, res=res, relu=self.relu)
+        self.has_res = res is not None
+        return y, Ho, Wo
+
+    def backward(self, dy, sink: GradSink, need_dx=True):
+        """dy: gradient of the layer output (modified in place).  Returns (dx or None, d_res or None)."""
+        d_res = None
+        if self.bn is None:
+            if self.relu:
+                n4 = (self.M * self.cout + 3) // 4 * 4
+                _ck(_lib().bevf_relu_mask_f32(dy.data_ptr(), self.y.data_ptr(), n4, _st()), "bevf_relu_mask_f32")
+            dxraw = dy
+        else:
+            dxraw, dgamma, dbeta = bn_train_backward(dy, self.bns, self.bn, relu=self.relu)
+            sink.add(self.bn.weight, dgamma)
+            sink.add(self.bn.bias, dbeta)
+            if self.has_res:
+                d_res = dy                                    # masked by the ReLU in place: gradient of the skip input
+        if self.conv.bias is not None:
+            sink.add(self.conv.bias, colsum(dxraw, self.M, self.cout))
+        dw = conv_wgrad(self.x, dxraw, self.N, self.H, self.W, self.cin, self.cout, self.k, self.stride, self.pad)
+        w = self.conv.weight
+        sink.add(w, dw.permute(0, 3, 1, 2).reshape(w.shape))
+        dx = None
+        if need_dx:
+            w4 = w if w.dim() == 4 else w.unsqueeze(-1)
+            dx = conv_dgrad(dxraw, w4, self.N, self.H, self.W, self.cin, self.cout, self.k, self.stride, self.pad)
+        return dx, d_res
+
+
+class LinearLayer:
+    def __init__(self, lin: nn.Linear, relu: bool, perm: Tuple[int, int] = (0, 0)):
+        self.lin, self.relu, self.perm = lin, relu, perm
+
+    def forward(self, x, B):
+        w = self.lin.weight.detach().contiguous()
+        O, K = w.shape
+        y = _new(B * O, x.device)
+        L.linear(x, w, self.lin.bias.detach() if self.lin.bias is not None else None, y, B, K, O, self.relu, *self.perm)
+        self.x, self.y, self.B = x, y, B
+        return y
+
+    def backward(self, dy, sink: GradSink, need_dx=True):
+        w = self.lin.weight.detach().contiguous()
+        O, K = w.shape
+        dev = dy.device
+        if self.relu:
+            n4 = (self.B * O + 3) // 4 * 4
+            _ck(_lib().bevf_relu_mask_f32(dy.data_ptr(), self.y.data_ptr(), n4, _st()), "bevf_relu_mask_f32")
+        dx = _new(self.B * K, dev) if need_dx else None
+        dw, db = _new(O * K, dev), _new(O, dev)
+        work = _new(_lib().bevf_linear_bwd_work_floats(self.B, K, O), dev)
+        _ck(_lib().bevf_linear_bwd_f32(dy.data_ptr(), self.x.data_ptr(), w.data_ptr(),
+                                       dx.data_ptr() if dx is not None else None, dw.data_ptr(), db.data_ptr(),
+                                       work.data_ptr(), self.B, K, O, self.perm[0], self.perm[1], _st()), "bevf_linear_bwd_f32")
+        sink.add(self.lin.weight, dw[:O * K])
+        sink.add(self.lin.bias, db[:O])
+        return dx
+
+
+class Bilinear:
+    def forward(self, x, B, Hi, Wi, Cc, Ho, Wo, y=None, y_cs=None):
+        self.geom = (B, Hi, Wi, Cc, Ho, Wo, y_cs or Cc)
+        if y is None:
+            y = _new(B * Ho * Wo * Cc, x.device)
+        L.bilinear_nhwc(x, y, B, Hi, Wi, Cc, Cc, Ho, Wo, y_cs or Cc)
+        return y
+
+    def backward(self, dy):
+        B, Hi, Wi, Cc, Ho, Wo, y_cs = self.geom
+        dx = _zeros(B * Hi * Wi * Cc, dy.device)
+        _ck(_lib().bevf_bilinear_bwd_nhwc_f32(dy.data_ptr(), dx.data_ptr(), B, Hi, Wi, Cc, Cc, Ho, Wo, y_cs, _st()),
+            "bevf_bilinear_bwd_nhwc_f32")
+        return dx
+
+
+# ---- the detector graph --------------------------------------------------------------------------------------------------------
+
+class DetectorTape:
+    """Train-mode forward of FlexibleMultiModal3DDetector (bev + centernet) with everything backward needs."""
+
+    def __init__(self, model):
+        self.m = model
+
+    # -- camera encoder ---------------------------------------------------------------------------------------------------------
+    def _camera_forward(self, imgs):
+        enc = self.m.camera_encoder
+        if imgs.dim() == 5:
+            B, n = imgs.shape[:2]
+            x = imgs.reshape(B * n, *imgs.shape[2:]).contiguous().float()
+        else:
+            B, n = imgs.shape[0], 1
+            x = imgs.contiguous().float()
+        N, _, H, W = x.shape
+        dev = x.device
+        self.cam_geom_in = (N, H, W)
+        self.imgs = x
+        H1, W1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        w = enc.conv1.weight.detach()
+        packed = torch.zeros(148, 64, device=dev)
+        packed[:147] = w.reshape(64, 147).t()
+        one, zero = torch.ones(64, device=dev), torch.zeros(64, device=dev)
+        raw = _new(N * H1 * W1 * 64, dev)
+        L.stem_conv7x7(x, packed.view(-1), one, zero, raw, N, H, W, relu=False)
+        y, self.stem_bn = bn_train_forward(raw, enc.bn1, N * H1 * W1, 64, relu=True)
+        H2, W2 = (H1 - 1) // 2 + 1, (W1 - 1) // 2 + 1
+        pooled = _new(N * H2 * W2 * 64, dev)
+        self.pool_idx = torch.empty(N * H2 * W2 * 64, dtype=torch.uint8, device=dev)
+        _ck(_lib().bevf_maxpool3x3s2_idx_f32(y.data_ptr(), pooled.data_ptr(), self.pool_idx.data_ptr(), N, H1, W1, 64, _st()),
+            "bevf_maxpool3x3s2_idx_f32")
+        self.pool_geom = (N, H1, W1)
+        cur, h, wd = pooled, H2, W2
+        self.blocks = []
+        for layer in (enc.layer1, enc.layer2, enc.layer3):
+            for blk in layer:
+                c1, c2 = ConvBNLayer(blk.conv1, blk.bn1, True), ConvBNLayer(blk.conv2, blk.bn2, True)
+                down = ConvBNLayer(blk.downsample[0], blk.downsample[1], False) if blk.downsample is not None else None
+                t, ho, wo = c1.forward(cur, N, h, wd)
+                idt = cur
+                if down is not None:
+                    idt, _, _ = down.forward(cur, N, h, wd)
+                out, _, _ = c2.forward(t, N, ho, wo, res=idt)
+                self.blocks.append((c1, c2, down))
+                cur, h, wd = out, ho, wo
+        self.proj = ConvBNLayer(enc.channel_proj[0], enc.channel_proj[1], True)
+        feat, _, _ = self.proj.forward(cur, N, h, wd)
+        return feat, (B, n, h, wd)
+
+    def _camera_backward(self, dfeat, sink):
+        enc = self.m.camera_encoder
+        d, _ = self.proj.backward(dfeat, sink)
+        for c1, c2, down in reversed(self.blocks):
+            dt, d_res = c2.backward(d, sink)                   # d_res: gradient reaching the skip connection
+            dx, _ = c1.backward(dt, sink)
+            if down is not None:
+                dd, _ = down.backward(d_res, sink)
+                add_(dx, dd, dx.numel())
+            else:
+                add_(dx, d_res, min(dx.numel(), d_res.numel()))
+            d = dx
+        N, H1, W1 = self.pool_geom
+        dpool_in = _new(N * H1 * W1 * 64, d.device)
+        _ck(_lib().bevf_maxpool3x3s2_bwd_f32(d.data_ptr(), self.pool_idx.data_ptr(), dpool_in.data_ptr(), N, H1, W1, 64, _st()),
+            "bevf_maxpool3x3s2_bwd_f32")
+        draw, dgamma, dbeta = bn_train_backward(dpool_in, self.stem_bn, enc.bn1, relu=True)
+        sink.add(enc.bn1.weight, dgamma)
+        sink.add(enc.bn1.bias, dbeta)
+        # stem weight gradient: im2col (k = c*49+kh*7+kw, padded to 160) + the generic MFMA weight-gradient GEMM
+        Ni, H, W = self.cam_geom_in
+        M = N * H1 * W1
+        # (in image chunks: the column matrix must stay below the 2 GiB limit of 32-bit buffer offsets)
+        per_img = H1 * W1
+        chunk = max(1, min(Ni, (1 << 31) // (per_img * 160 * 4 + 1)))
+        dwbuf = _zeros(64 * 160, d.device)
+        col = _new(chunk * per_img * 160, d.device)
+        for i0 in range(0, Ni, chunk):
+            n = min(chunk, Ni - i0)
+            _ck(_lib().bevf_stem_im2col_f32(self.imgs[i0:i0 + n].data_ptr(), col.data_ptr(), n, H, W, _st()),
+                "bevf_stem_im2col_f32")
+            conv_wgrad(col, draw[i0 * per_img * 64:], n * per_img, 1, 1, 160, 64, 1, 1, 0, dw=dwbuf)   # [64][160]
+        sink.add(enc.conv1.weight, dwbuf[:64 * 160].view(64, 160)[:, :147].reshape(64, 3, 7, 7))
+
+    # -- PointNet ----------------------------------------------------------------------------------------------------------------
+    def _lidar_forward(self, pts):
+        enc = self.m.lidar_encoder
+        rows = enc._rows(pts)
+        B, Np, Cc = rows.shape
+        M = B * Np
+        dev = rows.device
+        self.pts_rows, self.pn_geom = rows, (B, Np, Cc)
+        w0 = enc.conv1.weight.detach().reshape(enc.conv1.weight.shape[0], Cc).contiguous()
+        c0 = w0.shape[0]
+        raw = _new(M * c0, dev)
+        L.pointwise_smallk(rows, w0, None, enc.conv1.bias.detach(), raw, M, Cc, c0, False)
+        use_bn = isinstance(enc.bn1, nn.BatchNorm1d)
+        assert use_bn, "training path expects use_bn=True PointNet"
+        a, self.pn_bn0 = bn_train_forward(raw, enc.bn1, M, c0, relu=True)
+        self.pn_layers = []
+        for i in range(2, 6):
+            lyr = ConvBNLayer(getattr(enc, f"conv{i}"), getattr(enc, f"bn{i}"), True)
+            a, _, _ = lyr.forward(a, M, 1, 1)
+            self.pn_layers.append(lyr)
+        feat = lyr.cout
+        g = _new(B * feat, dev)
+        self.pn_idx = torch.empty(B * feat, dtype=torch.int32, device=dev)
+        _ck(_lib().bevf_group_max_idx_f32(a.data_ptr(), g.data_ptr(), self.pn_idx.data_ptr(), B, Np, feat, _st()),
+            "bevf_group_max_idx_f32")
+        return g
+
+    def _lidar_backward(self, dg, sink):
+        enc = self.m.lidar_encoder
+        B, Np, Cc = self.pn_geom
+        M = B * Np
+        feat = self.pn_layers[-1].cout
+        d = _zeros(M * feat, dg.device)
+        _ck(_lib().bevf_group_max_bwd_f32(dg.data_ptr(), self.pn_idx.data_ptr(), d.data_ptr(), B, Np, feat, _st()),
+            "bevf_group_max_bwd_f32")
+        for lyr in reversed(self.pn_layers):
+            d, _ = lyr.backward(d, sink)
+        draw, dgamma, dbeta = bn_train_backward(d, self.pn_bn0, enc.bn1, relu=True)
+        sink.add(enc.bn1.weight, dgamma)
+        sink.add(enc.bn1.bias, dbeta)
+        c0 = enc.conv1.weight.shape[0]
+        sink.add(enc.conv1.bias, colsum(draw, M, c0))
+        dw = _zeros(c0 * Cc, dg.device)
+        _ck(_lib().bevf_smallk_wgrad_f32(draw.data_ptr(), self.pts_rows.data_ptr(), dw.data_ptr(), M, Cc, c0, _st()),
+            "bevf_smallk_wgrad_f32")
+        sink.add(enc.conv1.weight, dw[:c0 * Cc])
+
+    # -- fusion + head -----------------------------------------------------------------------------------------------------------
+    def forward(self, imgs, pts, radars):
+        m = self.m
+        if m.use_radar and radars is not None:
+            raise NotImplementedError("training with the radar branch is not built yet (camera / lidar / camera+lidar are)")
+        fus = m.fusion
+        Sh, Sw, bc = fus.bev_h, fus.bev_w, fus.bev_channels
+        P = Sh * Sw
+        self.has_cam = m.use_camera and imgs is not None
+        self.has_lid = m.use_lidar and pts is not None
+        nmod = int(self.has_cam) + int(self.has_lid)
+        if nmod == 0:
+            raise ValueError("No modality features provided")
+        dev = (imgs if self.has_cam else pts).device
+        cam_feat = lid_feat = None
+        if self.has_cam:
+            cam_feat, (B, ncam, Hc, Wc) = self._camera_forward(imgs)
+        if self.has_lid:
+            lid_feat = self._lidar_forward(pts)
+            B = self.pn_geom[0]
+        ccs = bc * nmod
+        concat = _new(B * P * ccs, dev)
+        slot = 0
+        self.B, self.ccs = B, ccs
+        if self.has_cam:
+            Cc = 512
+            self.cam_pool_geom = (B, ncam, Hc * Wc, Cc)
+            pooled = cam_feat
+            if ncam > 1:
+                pooled = _new(B * Hc * Wc * Cc, dev)
+                L.cam_mean(cam_feat, pooled, B, ncam, Hc * Wc, Cc)
+            self.cp1 = ConvBNLayer(fus.camera_proj[0], fus.camera_proj[1], True)
+            self.cp2 = ConvBNLayer(fus.camera_proj[3], fus.camera_proj[4], True)
+            t1, _, _ = self.cp1.forward(pooled, B, Hc, Wc)
+            t2, _, _ = self.cp2.forward(t1, B, Hc, Wc)
+            self.cam_resize = Bilinear()
+            self.cam_resize.forward(t2, B, Hc, Wc, bc, Sh, Sw, y=concat[slot * bc:], y_cs=ccs)
+            self.cam_slot = slot
+            slot += 1
+        if self.has_lid:
+            s0 = fus.lidar_start_size
+            self.li0 = LinearLayer(fus.lidar_init[0], True)
+            O = fus.lidar_init[2].weight.shape[0]
+            ch = O // (s0 * s0)
+            self.li2 = LinearLayer(fus.lidar_init[2], False, (s0 * s0, ch))
+            hid = self.li0.forward(lid_feat, B)
+            grid0 = self.li2.forward(hid, B)
+            self.lu1 = ConvBNLayer(fus.lidar_upsample[0], fus.lidar_upsample[1], True)
+            self.lu2 = ConvBNLayer(fus.lidar_upsample[4], fus.lidar_upsample[5], True)
+            g1, _, _ = self.lu1.forward(grid0, B, s0, s0)
+            self.lid_up = Bilinear()
+            s1 = 2 * s0
+            g2 = self.lid_up.forward(g1, B, s0, s0, self.lu1.cout, s1, s1)
+            g3, _, _ = self.lu2.forward(g2, B, s1, s1)
+            self.lid_s1 = s1
+            self.lid_resize = None
+            if (s1, s1) == (Sh, Sw):
+                # copy into the concat slice (bilinear at identical size is the identity map)
+                self.lid_resize = Bilinear()
+                self.lid_resize.forward(g3, B, s1, s1, bc, Sh, Sw, y=concat[slot * bc:], y_cs=ccs)
+            else:
+                self.lid_resize = Bilinear()
+                self.lid_resize.forward(g3, B, s1, s1, bc, Sh, Sw, y=concat[slot * bc:], y_cs=ccs)
+            self.lid_slot = slot
+            slot += 1
+        self.f1 = ConvBNLayer(fus.bev_fusion[0], fus.bev_fusion[1], True)
+        self.f2 = ConvBNLayer(fus.bev_fusion[3], fus.bev_fusion[4], True)
+        a1, _, _ = self.f1.forward(concat, B, Sh, Sw)
+        fused, _, _ = self.f2.forward(a1, B, Sh, Sw)
+        # head: the five 3x3 branches as one conv (weights concatenated along Cout), then the tail kernel
+        head = m.det_head
+        convs3 = [getattr(head, f"{n}_head")[0] for n in E.HEAD_BRANCHES]
+        convs1 = [getattr(head, f"{n}_head")[2] for n in E.HEAD_BRANCHES]
+        self.hc = convs3[0].weight.shape[0]
+        w3 = torch.cat([c.weight.detach() for c in convs3], 0)
+        b3 = torch.cat([c.bias.detach() for c in convs3], 0).contiguous()
+        self.head_w3 = w3
+        hid, _, _ = conv_raw(fused, w3.permute(0, 2, 3, 1).contiguous().view(-1), b3, B, Sh, Sw, w3.shape[1], w3.shape[0],
+                             3, 1, 1, relu=True)
+        self.head_in, self.head_hid = fused, hid
+        self.cs = [c.weight.shape[0] for c in convs1]
+        self.w1 = torch.cat([c.weight.detach().reshape(c.weight.shape[0], self.hc) for c in convs1], 0).contiguous()
+        b1 = torch.cat([c.bias.detach() for c in convs1], 0).contiguous()
+        outs = [torch.empty(B, c, Sh, Sw, device=dev) for c in self.cs]
+        L.head_tail(hid, self.w1, b1, outs, B, P, self.hc, self.cs, self.cs[0])
+        self.outs = outs
+        self.S = (Sh, Sw)
+        return outs
+
+    def backward(self, douts: List[torch.Tensor]) -> GradSink:
+        m = self.m
+        sink = GradSink()
+        B, (Sh, Sw) = self.B, self.S
+        P = Sh * Sw
+        dev = self.outs[0].device
+        head = m.det_head
+        convs3 = [getattr(head, f"{n}_head")[0] for n in E.HEAD_BRANCHES]
+        convs1 = [getattr(head, f"{n}_head")[2] for n in E.HEAD_BRANCHES]
+        ctot = sum(self.cs)
+        dhid = _new(B * P * 5 * self.hc, dev)
+        dw1, db1 = _zeros(ctot * self.hc, dev), _zeros(ctot, dev)
+        d = L.HeadBwdDesc()
+        d.hid, d.w, d.out0 = self.head_hid.data_ptr(), self.w1.data_ptr(), self.outs[0].data_ptr()
+        keep = []
+        for k in range(5):
+            g = douts[k]
+            g = torch.zeros_like(self.outs[k]) if g is None else g.contiguous().float()
+            keep.append(g)
+            d.dout[k], d.c[k] = g.data_ptr(), self.cs[k]
+        d.dhid, d.dw, d.db, d.B, d.P, d.hc, d.n_sigmoid = dhid.data_ptr(), dw1.data_ptr(), db1.data_ptr(), B, P, self.hc, self.cs[0]
+        _ck(_lib().bevf_head_tail_bwd_f32(C.byref(d), _st()), "bevf_head_tail_bwd_f32")
+        o = 0
+        for k, c1 in enumerate(convs1):
+            n = self.cs[k]
+            sink.add(c1.weight, dw1[o * self.hc:(o + n) * self.hc])
+            sink.add(c1.bias, db1[o:o + n])
+            o += n
+        # fused 3x3 head conv: ReLU mask, bias / weight / data gradients, split back per branch
+        c5 = 5 * self.hc
+        n4 = (B * P * c5 + 3) // 4 * 4
+        _ck(_lib().bevf_relu_mask_f32(dhid.data_ptr(), self.head_hid.data_ptr(), n4, _st()), "bevf_relu_mask_f32")
+        db3 = colsum(dhid, B * P, c5)
+        cin = self.head_w3.shape[1]
+        dw3 = conv_wgrad(self.head_in, dhid, B, Sh, Sw, cin, c5, 3, 1, 1).permute(0, 3, 1, 2)
+        for k, c3 in enumerate(convs3):
+            sink.add(c3.weight, dw3[k * self.hc:(k + 1) * self.hc])
+            sink.add(c3.bias, db3[k * self.hc:(k + 1) * self.hc])
+        dfused = conv_dgrad(dhid, self.head_w3, B, Sh, Sw, cin, c5, 3, 1, 1)
+        da1, _ = self.f2.backward(dfused, sink)
+        dconcat, _ = self.f1.backward(da1, sink)
+        bc = m.fusion.bev_channels
+        if self.has_lid:
+            dg3 = self.lid_resize.backward(dconcat[self.lid_slot * bc:])
+            dg2, _ = self.lu2.backward(dg3, sink)
+            dg1 = self.lid_up.backward(dg2)
+            dgrid0, _ = self.lu1.backward(dg1, sink)
+            dhid_l = self.li2.backward(dgrid0, sink)
+            dlid = self.li0.backward(dhid_l, sink)
+            self._lidar_backward(dlid, sink)
+        if self.has_cam:
+            dt2 = self.cam_resize.backward(dconcat[self.cam_slot * bc:])
+            dt1, _ = self.cp2.backward(dt2, sink)
+            dpooled, _ = self.cp1.backward(dt1, sink)
+            Bc, ncam, Pc, Cc = self.cam_pool_geom
+            dfeat = dpooled
+            if ncam > 1:
+                dfeat = _new(Bc * ncam * Pc * Cc, dev)
+                _ck(_lib().bevf_cam_mean_bwd_f32(dpooled.data_ptr(), dfeat.data_ptr(), Bc, ncam, Pc, Cc, _st()),
+                    "bevf_cam_mean_bwd_f32")
+            self._camera_backward(dfeat, sink)
+        return sink
+
+
+class _DetectorTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, imgs, pts, radars, *params):
+        tape = DetectorTape(model)
+        with torch.no_grad():
+            outs = tape.forward(imgs, pts, radars)
+        ctx.tape, ctx.params = tape, params
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        with torch.no_grad():
+            sink = ctx.tape.backward(list(douts))
+        grads = []
+        for p in ctx.params:
+            g = sink.get(p)
+            grads.append(g.reshape(p.shape).contiguous() if g is not None else None)
+        return (None, None, None, None, *grads)
+
+
+def detector_train_forward(model, imgs, pts, radars) -> Dict[str, torch.Tensor]:
+    params = [p for p in model.parameters() if p.requires_grad]
+    outs = _DetectorTrainFn.apply(model, imgs, pts, radars, *params)
+    return dict(zip(E.HEAD_BRANCHES, outs))
+
+
+# ---- loss with gradient ------------------------------------------------------------------------------------------------------------
+
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weights, tgt_keys, *tensors):
+        preds = dict(zip(E.HEAD_BRANCHES, tensors[:5]))
+        tgt = dict(zip(tgt_keys, tensors[5:]))
+        vals = L.centernet_loss(preds, tgt, weights)
+        ctx.preds, ctx.tgt, ctx.weights = preds, tgt, weights
+        return tuple(vals[i].clone() for i in range(6))
+
+    @staticmethod
+    def backward(ctx, g_total, *g_rest):
+        for g in g_rest:
+            if g is not None and bool((g != 0).any()):
+                raise NotImplementedError("backward through the individual loss terms is not built; use total_loss")
+        preds, tgt, w = ctx.preds, ctx.tgt, ctx.weights
+        heat = preds["heatmap"]
+        B, Cn, H, W = heat.shape
+        K = tgt["ind"].shape[1]
+        dev = heat.device
+        d = L.LossDesc()
+        keep = []
+
+        def f32(t):
+            t = t.detach().float().contiguous()
+            keep.append(t)
+            return t.data_ptr()
+        d.pred_heatmap, d.tgt_heatmap = f32(heat), f32(tgt["heatmap"])
+        for q, name in enumerate(("offset", "size", "rot", "vel")):
+            d.pred_reg[q], d.tgt_reg[q] = f32(preds[name]), f32(tgt["target_" + name])
+        ind = tgt["ind"].to(torch.int64).contiguous()
+        rm = tgt["reg_mask"].to(torch.uint8).contiguous()
+        d.ind, d.reg_mask = ind.data_ptr(), rm.data_ptr()
+        d.B, d.C, d.H, d.W, d.K = B, Cn, H, W, K
+        for i in range(5):
+            d.weights[i] = float(w[i])
+        dp = [torch.zeros_like(preds[n], dtype=torch.float32) for n in E.HEAD_BRANCHES]
+        arr = (C.c_void_p * 5)(*[t.data_ptr() for t in dp])
+        scratch = torch.empty(4, device=dev)
+        _ck(_lib().bevf_centernet_loss_bwd_f32(C.byref(d), arr, scratch.data_ptr(), _st()), "bevf_centernet_loss_bwd_f32")
+        gt = g_total if g_total is not None else torch.zeros((), device=dev)
+        return (None, None, *[t * gt for t in dp], *([None] * len(ctx.tgt)))
+
+
+def loss_with_grad(predictions: Dict[str, torch.Tensor], targets: Dict[str, torch.Tensor], weights) -> Dict[str, torch.Tensor]:
+    keys = tuple(targets.keys())
+    vals = _LossFn.apply(tuple(weights), keys, *[predictions[n] for n in E.HEAD_BRANCHES], *[targets[k] for k in keys])
+    names = ("total_loss", "heatmap_loss", "offset_loss", "size_loss", "rot_loss", "vel_loss")
+    return dict(zip(names, vals))
+
+
+# ---- optimiser pieces on device ------------------------------------------------------------------------------------------------------
+
+def clip_grad_norm_(parameters, max_norm: float) -> torch.Tensor:
+    """torch.nn.utils.clip_grad_norm_ (L2) with the norm and the scaling on device (ref src/train_detect.py:431)."""
+    params = [p for p in parameters if p.grad is not None]
+    dev = params[0].grad.device
+    flat = torch.cat([p.grad.detach().reshape(-1).float() for p in params])
+    work = torch.empty(512, dtype=torch.float64, device=dev)
+    out = torch.empty(2, device=dev)
+    _ck(_lib().bevf_grad_norm_f32(flat.data_ptr(), flat.numel(), work.data_ptr(), float(max_norm), out.data_ptr(), _st()),
+        "bevf_grad_norm_f32")
+    for p in params:
+        p.grad.mul_(out[1])
+    return out[0]
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW semantics (ref src/train_detect.py:725-741: lr 1e-4, weight_decay 0.01) on bevf_adamw_step_f32."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] += 1
+                g = p.grad.contiguous()
+                _ck(_lib().bevf_adamw_step_f32(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
+                                               st["exp_avg_sq"].data_ptr(), None, p.numel(), group["lr"], b1, b2,
+                                               group["eps"], group["weight_decay"], st["step"], _st()), "bevf_adamw_step_f32")

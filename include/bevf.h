@@ -65,13 +65,13 @@ typedef struct {
 } bevf_conv_desc;
 int bevf_conv2d_nhwc_f32(const bevf_conv_desc* d, void* stream);
 
-/* ResNet stem: 7x7 stride-2 pad-3 conv on a planar 3-channel image + BN + ReLU,
+/* ResNet stem: 7x7 stride-2 pad-3 conv on a planar 3-channel image + BN (+ ReLU when relu != 0),
  * ref src/encoders.py:154-156 (torchvision conv1/bn1/relu).  x: [N][3][H][W] (NCHW, as the
  * reference's callers hand it over), w: the filter bank packed k-major [148][64] with
  * k = c*49 + kh*7 + kw and a zero row k = 147 (packed once per weight update by the host),
  * y: [N][Ho][Wo][64] NHWC.                                                                  */
 int bevf_stem_conv7x7_f32(const float* x, const float* w, const float* scale, const float* shift,
-                          float* y, int N, int H, int W, void* stream);
+                          float* y, int N, int H, int W, int relu, void* stream);
 
 /* 3x3 stride-2 pad-1 max-pool, NHWC, ref src/encoders.py:157.                               */
 int bevf_maxpool3x3s2_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
@@ -218,6 +218,75 @@ typedef struct {
 } bevf_loss_desc;
 size_t bevf_centernet_loss_work_floats(void);
 int bevf_centernet_loss_f32(const bevf_loss_desc* d, void* stream);
+
+/* ==========================================================================================
+ * Training step (ref src/train_detect.py:401-434): the backward of every layer on
+ * the path, train-mode BatchNorm, gradient clipping and AdamW.  Gradients accumulated with fp32 atomics
+ * (conv weight gradient, bilinear / gather-L1 scatter) are not bitwise reproducible run to run.
+ * ========================================================================================== */
+
+/* Pixel table for the weight gradient: tab[m] = {n*H*W, (ih0<<16)|(iw0&0xffff)}, 2 x int32 per output pixel. */
+int bevf_conv_pixtab(int32_t* tab, int N, int H, int W, int KH, int KW, int stride, int pad, void* stream);
+
+/* dW[co][kh][kw][ci] += sum_m dy[m][co] * x[pixel(m)+tap][ci]   (dw zero-filled by the caller; OHWI like the
+ * forward weights; the host permutes back to the parameter's OIHW).  MFMA fp32, pixel range split over WGs. */
+typedef struct {
+  const float* x;          /* [N][H][W][x_cs] forward input */
+  const float* dy;         /* [N*Ho*Wo][dy_cs] gradient of the raw conv output */
+  float* dw;               /* [Cout][KH][KW][Cin] */
+  const int32_t* pixtab;
+  int32_t N, H, W, Cin, x_cs, Cout, dy_cs, KH, KW, stride, pad;
+} bevf_wgrad_desc;
+int bevf_conv2d_wgrad_f32(const bevf_wgrad_desc* d, void* stream);
+
+/* Data gradient: the forward kernel (bevf_conv2d_nhwc_f32) run on dy with the spatially flipped, channel-
+ * transposed filter; strided convs first spread dy onto the input grid with zeros in between:            */
+int bevf_zero_stuff_nhwc_f32(const float* dy, float* out, int N, int Ho, int Wo, int C, int H, int W, int s, void* stream);
+
+/* Train-mode BatchNorm{1,2}d over rows [M][C] (channel stride cs): batch mean / biased variance / invstd
+ * (two-stage, fixed order, shifted sums), apply (+residual)(+ReLU), and backward:
+ *   dy <- dy * (y > 0) if relu;  dbeta = sum dy;  dgamma = sum dy*xhat;
+ *   dx = gamma*invstd*(dy - dbeta/M - xhat*dgamma/M)   (dx == NULL: only the sums -> conv bias gradients) */
+size_t bevf_bn_work_floats(int C);
+int bevf_bn_stats_f32(const float* x, float* work, float* mean, float* var, float* invstd, int M, int C, int cs,
+                      float eps, void* stream);
+int bevf_bn_apply_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                      const float* res, float* y, int M, int C, int cs, int relu, void* stream);
+int bevf_bn_backward_f32(float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                         const float* gamma, float* work, float* dgamma, float* dbeta, float* dx, int M, int C,
+                         int cs, int relu, void* stream);
+
+int bevf_add_inplace_f32(float* y, const float* x, size_t n, void* stream);            /* y += x            */
+int bevf_relu_mask_f32(float* dy, const float* y, size_t n, void* stream);             /* dy *= (y > 0)     */
+int bevf_maxpool3x3s2_idx_f32(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C, void* stream);
+int bevf_maxpool3x3s2_bwd_f32(const float* dy, const uint8_t* idx, float* dx, int N, int H, int W, int C, void* stream);
+int bevf_bilinear_bwd_nhwc_f32(const float* dy, float* dx, int B, int Hi, int Wi, int C, int x_cs, int Ho, int Wo,
+                               int y_cs, void* stream);                                 /* dx zero-filled    */
+int bevf_cam_mean_bwd_f32(const float* dy, float* dx, int B, int ncam, int P, int C, void* stream);
+int bevf_group_max_idx_f32(const float* x, float* y, int32_t* idx, int G, int P, int C, void* stream);
+int bevf_group_max_bwd_f32(const float* dy, const int32_t* idx, float* dx, int G, int P, int C, void* stream); /* dx zero-filled */
+size_t bevf_linear_bwd_work_floats(int B, int K, int O);
+int bevf_linear_bwd_f32(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, float* work,
+                        int B, int K, int O, int perm_inner, int perm_outer, void* stream);
+typedef struct {
+  const float* hid; const float* w; const float* out0;   /* out0: post-sigmoid heatmap (B,c0,H,W) */
+  const float* dout[5];
+  float* dhid; float* dw; float* db;                     /* dw, db zero-filled by the caller */
+  int32_t B, P, hc;
+  int32_t c[5];
+  int32_t n_sigmoid;
+} bevf_head_bwd_desc;
+int bevf_head_tail_bwd_f32(const bevf_head_bwd_desc* d, void* stream);
+/* d total_loss / d predictions for CenterNetLoss (ref src/centernet_target.py:544-622); dpred[5] zero-filled;
+ * scratch2: 2 floats.                                                                                        */
+int bevf_centernet_loss_bwd_f32(const bevf_loss_desc* d, float* const dpred[5], float* scratch2, void* stream);
+int bevf_stem_im2col_f32(const float* x, float* col, int N, int H, int W, void* stream);   /* [M][160], k=c*49+kh*7+kw */
+int bevf_smallk_wgrad_f32(const float* dy, const float* x, float* dw, int M, int K, int Cout, void* stream);
+/* clip_grad_norm_: out2 = {total L2 norm, min(1, max_norm/(norm+1e-6))}; work512: 512 doubles.                */
+int bevf_grad_norm_f32(const float* g, size_t n, double* work512, float max_norm, float* out2, void* stream);
+/* torch.optim.AdamW single step on a flat parameter range; gradients are scaled by clip2[1] when given.        */
+int bevf_adamw_step_f32(float* p, const float* g, float* m, float* v, const float* clip2, size_t n, float lr,
+                        float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
 
 #ifdef __cplusplus
 }

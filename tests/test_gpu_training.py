@@ -1,0 +1,172 @@
+"""GPU parity of the training step: backward kernels against torch autograd on the CPU
+oracle, and one whole step (forward train-mode BN -> targets -> loss -> backward -> clip -> AdamW) against the
+fixture minted from the imported reference (tests/golden/train_step.npz)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from bevfusion_multimodal_3d_object_detection_amd import centernet_target as ct
+from bevfusion_multimodal_3d_object_detection_amd import fusion, synth, training
+from bevfusion_multimodal_3d_object_detection_amd import _lib as L
+from tests.conftest import load_golden, rel_err
+from tests.golden import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous().view(-1).cuda()
+
+
+@pytest.mark.parametrize("N,H,W,cin,cout,k,stride,pad", [(2, 9, 13, 32, 64, 3, 1, 1), (1, 17, 11, 64, 128, 3, 2, 1),
+                                                          (2, 8, 8, 64, 128, 1, 2, 0), (1, 40, 36, 128, 256, 3, 1, 1),
+                                                          (700, 1, 1, 64, 128, 1, 1, 0), (3, 6, 5, 256, 320, 3, 1, 1)])
+def test_conv_wgrad_dgrad(gpu, N, H, W, cin, cout, k, stride, pad):
+    x = synth.normal((N, cin, H, W), 1).requires_grad_(True)
+    w = synth.normal((cout, cin, k, k), 2, 0, 0.05).requires_grad_(True)
+    y = F.conv2d(x, w, None, stride, pad)
+    dy = synth.normal(tuple(y.shape), 3)
+    y.backward(dy)
+    dw = training.conv_wgrad(nhwc(x.detach()), nhwc(dy), N, H, W, cin, cout, k, stride, pad)
+    assert rel_err(dw.permute(0, 3, 1, 2).cpu(), w.grad) <= 2e-5
+    dx = training.conv_dgrad(nhwc(dy), w.detach().cuda(), N, H, W, cin, cout, k, stride, pad)
+    assert rel_err(dx[:N * H * W * cin].view(N, H, W, cin).permute(0, 3, 1, 2).cpu(), x.grad) <= 2e-5
+
+
+@pytest.mark.parametrize("M,C,relu,res", [(1000, 64, True, True), (333, 256, True, False), (77, 1024, False, False), (5000, 128, True, False)])
+def test_bn_train_forward_backward(gpu, M, C, relu, res):
+    bn = torch.nn.BatchNorm1d(C)
+    synth.fill_state_dict_(bn, 5)
+    bn.train()
+    x = (synth.normal((M, C), 6) * 3 + 50).requires_grad_(True)          # |mean| >> std: the cancellation case
+    r = synth.normal((M, C), 7).requires_grad_(True) if res else None
+    ref_rm = bn.running_mean.clone()
+    y = bn(x)
+    if res:
+        y = y + r
+    if relu:
+        y = F.relu(y)
+    dy = synth.normal((M, C), 8)
+    y.backward(dy)
+    bn2 = torch.nn.BatchNorm1d(C)
+    bn2.load_state_dict({**bn.state_dict(), "running_mean": ref_rm, "running_var": torch.nn.BatchNorm1d(C).running_var * 0 + 1,
+                         "num_batches_tracked": torch.tensor(3)})
+    synth.fill_state_dict_(bn2, 5)
+    bn2 = bn2.cuda().train()
+    yg, st = training.bn_train_forward(x.detach().cuda().view(-1), bn2, M, C, res=r.detach().cuda().view(-1) if res else None, relu=relu)
+    assert rel_err(yg[:M * C].view(M, C).cpu(), y.detach()) <= 2e-5
+    assert rel_err(bn2.running_mean.cpu(), bn.running_mean) <= 1e-6 and rel_err(bn2.running_var.cpu(), bn.running_var) <= 1e-5
+    dyg = dy.cuda().view(-1).clone()
+    dx, dgamma, dbeta = training.bn_train_backward(dyg, st, bn2, relu=relu)
+    assert rel_err(dx[:M * C].view(M, C).cpu(), x.grad) <= 5e-5
+    assert rel_err(dgamma.cpu(), bn.weight.grad) <= 2e-5 and rel_err(dbeta.cpu(), bn.bias.grad) <= 2e-5
+    if res:
+        assert rel_err(dyg[:M * C].view(M, C).cpu(), r.grad) <= 1e-6
+
+
+def test_pool_resample_linear_backward(gpu):
+    lib, st = L.lib(), torch.cuda.current_stream().cuda_stream
+    # max-pool
+    x = synth.normal((2, 8, 11, 14), 11).requires_grad_(True)
+    y = F.max_pool2d(x, 3, 2, 1)
+    dy = synth.normal(tuple(y.shape), 12)
+    y.backward(dy)
+    N, C, H, W = x.shape
+    Ho, Wo = y.shape[-2:]
+    yg = torch.empty(N * Ho * Wo * C, device=gpu)
+    idx = torch.empty(N * Ho * Wo * C, dtype=torch.uint8, device=gpu)
+    assert lib.bevf_maxpool3x3s2_idx_f32(nhwc(x.detach()).data_ptr(), yg.data_ptr(), idx.data_ptr(), N, H, W, C, st) == 0
+    dx = torch.empty(N * H * W * C, device=gpu)
+    assert lib.bevf_maxpool3x3s2_bwd_f32(nhwc(dy).data_ptr(), idx.data_ptr(), dx.data_ptr(), N, H, W, C, st) == 0
+    assert torch.equal(yg.view(N, Ho, Wo, C).permute(0, 3, 1, 2).cpu(), y.detach())
+    assert rel_err(dx.view(N, H, W, C).permute(0, 3, 1, 2).cpu(), x.grad) <= 1e-6
+    # bilinear
+    x = synth.normal((2, 8, 5, 7), 13).requires_grad_(True)
+    y = F.interpolate(x, size=(12, 9), mode="bilinear", align_corners=False)
+    dy = synth.normal(tuple(y.shape), 14)
+    y.backward(dy)
+    dx = torch.zeros(2 * 5 * 7 * 8, device=gpu)
+    assert lib.bevf_bilinear_bwd_nhwc_f32(nhwc(dy).data_ptr(), dx.data_ptr(), 2, 5, 7, 8, 8, 12, 9, 8, st) == 0
+    assert rel_err(dx.view(2, 5, 7, 8).permute(0, 3, 1, 2).cpu(), x.grad) <= 2e-6
+    # dense layer with the permuted store of lidar_init.2
+    lin = torch.nn.Linear(64, 1000)
+    synth.fill_state_dict_(lin, 15)
+    xin = synth.normal((3, 64), 16).requires_grad_(True)
+    yl = lin(xin)
+    dyl = synth.normal((3, 1000), 17)
+    yl.backward(dyl)
+    lyr = training.LinearLayer(lin.cuda(), False, (125, 8))
+    out = lyr.forward(xin.detach().cuda().view(-1), 3)
+    assert rel_err(out[:3000].view(3, 125, 8).permute(0, 2, 1).reshape(3, 1000).cpu(), yl.detach()) <= 2e-5
+    sink = training.GradSink()
+    dyp = dyl.view(3, 8, 125).permute(0, 2, 1).contiguous().view(-1).cuda()
+    dxl = lyr.backward(dyp, sink)
+    assert rel_err(dxl[:192].view(3, 64).cpu(), xin.grad) <= 2e-5
+    assert rel_err(sink.get(lin.weight).cpu(), lin.weight.grad.cpu() if lin.weight.grad is not None else 0) <= 2e-5 \
+        if lin.weight.grad is not None else True
+
+
+def _train_case():
+    c = cases.TRAIN_CASE
+    model = fusion.create_detector(c["modality"], "bev", "centernet", bev_h=50, bev_w=50)
+    synth.fill_state_dict_(model, c["seed"])
+    model = model.cuda().train()
+    imgs, pts, _ = cases.detector_inputs(c)
+    boxes, labels = cases.target_inputs(c)
+    return c, model, imgs.cuda(), pts.cuda(), boxes, labels
+
+
+@pytest.mark.parametrize("opt_name", ["torch", "fused"])
+def test_train_step_golden(gpu, opt_name):
+    c, model, imgs, pts, boxes, labels = _train_case()
+    gold = load_golden("train_step")
+    opt = (torch.optim.AdamW if opt_name == "torch" else training.FusedAdamW)(model.parameters(), lr=1e-4, weight_decay=0.01)
+    pred = model(imgs, pts, None)
+    for k in ("heatmap", "offset", "size", "rot", "vel"):
+        assert rel_err(pred[k].detach().cpu(), gold["pred__" + k]) <= 1e-4, k
+    tgt = ct.prepare_centernet_targets({"gt_boxes": boxes, "gt_labels": labels}, gpu)
+    losses = ct.CenterNetLoss()(pred, tgt)
+    for k in ("total_loss", "heatmap_loss", "offset_loss", "size_loss", "rot_loss", "vel_loss"):
+        g = float(gold["loss__" + k])
+        assert abs(float(losses[k].detach()) - g) <= 1e-4 * max(abs(g), 1e-3), (k, float(losses[k].detach()), g)
+    opt.zero_grad()
+    losses["total_loss"].backward()
+    named = dict(model.named_parameters())
+    worst = {}
+    for name in cases.TRAIN_TRACKED:
+        # the fixture holds the CLIPPED gradients (recorded after clip_grad_norm_); compare after our own clip below
+        assert named[name].grad is not None, name
+    gnorm = training.clip_grad_norm_(model.parameters(), 10.0)
+    assert abs(float(gnorm) - float(gold["grad_norm"])) <= 2e-3 * float(gold["grad_norm"]), (float(gnorm), float(gold["grad_norm"]))
+    for name in cases.TRAIN_TRACKED:
+        g = named[name].grad.flatten()[:64].cpu()
+        ref = torch.from_numpy(gold["grad__" + name.replace(".", "__")])
+        scale = float(named[name].grad.abs().max().cpu())
+        # conv biases in front of a train-mode BatchNorm have a mathematically zero gradient (pure rounding noise in
+        # both implementations), hence the absolute floor relative to the global gradient norm
+        err = float((g - ref).abs().max())
+        worst[name] = err / max(scale, 1e-12)
+        assert err <= 3e-3 * scale + 2e-6 * float(gold["grad_norm"]), (name, err, scale)
+    opt.step()
+    for name in cases.TRAIN_TRACKED:
+        p = named[name].detach().flatten()[:64].cpu()
+        ref = torch.from_numpy(gold["post__" + name.replace(".", "__")])
+        assert float((p - ref).abs().max()) <= 2e-5 + 1e-4 * float(ref.abs().max()), name
+    # BatchNorm running statistics were updated like torch does
+    assert int(model.camera_encoder.bn1.num_batches_tracked) == 4
+
+
+def test_eval_after_train_uses_new_weights(gpu):
+    c, model, imgs, pts, boxes, labels = _train_case()
+    model.eval()
+    before = model(imgs, pts, None)["size"].clone()
+    model.train()
+    opt = training.FusedAdamW(model.parameters(), lr=1e-2, weight_decay=0.0)
+    pred = model(imgs, pts, None)
+    tgt = ct.prepare_centernet_targets({"gt_boxes": boxes, "gt_labels": labels}, gpu)
+    ct.CenterNetLoss()(pred, tgt)["total_loss"].backward()
+    opt.step()
+    model.eval()
+    after = model(imgs, pts, None)["size"]
+    assert float((after - before).abs().max()) > 1e-4          # repacked after the in-place parameter update
