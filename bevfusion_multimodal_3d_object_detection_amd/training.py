@@ -400,27 +400,89 @@ class DetectorTape:
             "bevf_smallk_wgrad_f32")
         sink.add(enc.conv1.weight, dw[:c0 * Cc])
 
+    # -- radar: shared per-sweep MLP + max, concat -> Linear (ref src/encoders.py:628-661) --------------------------------------
+    def _radar_forward(self, radars):
+        renc = self.m.radar_encoder
+        if renc.fusion_method != "concat":
+            raise NotImplementedError("training is built for fusion_method='concat' (the reference's default)")
+        enc = renc.radar_encoder
+        self.rad_sweeps = []
+        feats = []
+        for pts in radars:
+            rows = enc._rows(pts)
+            B, Np, Cc = rows.shape
+            M = B * Np
+            w0 = enc.conv1.weight.detach().reshape(enc.conv1.weight.shape[0], Cc).contiguous()
+            c0 = w0.shape[0]
+            raw = _new(M * c0, rows.device)
+            L.pointwise_smallk(rows, w0, None, enc.conv1.bias.detach(), raw, M, Cc, c0, False)
+            a, bn0 = bn_train_forward(raw, enc.bn1, M, c0, relu=True)
+            layers = []
+            for i in range(2, 5):
+                lyr = ConvBNLayer(getattr(enc, f"conv{i}"), getattr(enc, f"bn{i}"), True)
+                a, _, _ = lyr.forward(a, M, 1, 1)
+                layers.append(lyr)
+            feat = layers[-1].cout
+            g = _new(B * feat, rows.device)
+            idx = torch.empty(B * feat, dtype=torch.int32, device=rows.device)
+            _ck(_lib().bevf_group_max_idx_f32(a.data_ptr(), g.data_ptr(), idx.data_ptr(), B, Np, feat, _st()),
+                "bevf_group_max_idx_f32")
+            feats.append(g[:B * feat].view(B, feat))
+            self.rad_sweeps.append((rows, bn0, layers, idx, (B, Np, Cc, c0, feat)))
+        per = torch.stack(feats, dim=1).contiguous()                      # (B, R, feat) -- layout copy only
+        B, R, feat = per.shape
+        if R * feat != renc.fusion_fc.weight.shape[1]:
+            raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({B}x{R * feat} and "
+                               f"{renc.fusion_fc.weight.shape[1]}x{renc.fusion_fc.weight.shape[0]})")
+        self.rad_fc = LinearLayer(renc.fusion_fc, False)
+        return self.rad_fc.forward(per.view(-1), B), B
+
+    def _radar_backward(self, dfeat, sink):
+        enc = self.m.radar_encoder.radar_encoder
+        dper = self.rad_fc.backward(dfeat, sink)                            # [B][R][feat]
+        R = len(self.rad_sweeps)
+        for r in reversed(range(R)):
+            rows, bn0, layers, idx, (B, Np, Cc, c0, feat) = self.rad_sweeps[r]
+            M = B * Np
+            dg = dper[:B * R * feat].view(B, R, feat)[:, r].contiguous().view(-1)
+            d = _zeros(M * feat, dg.device)
+            _ck(_lib().bevf_group_max_bwd_f32(dg.data_ptr(), idx.data_ptr(), d.data_ptr(), B, Np, feat, _st()),
+                "bevf_group_max_bwd_f32")
+            for lyr in reversed(layers):
+                d, _ = lyr.backward(d, sink)
+            draw, dgamma, dbeta = bn_train_backward(d, bn0, enc.bn1, relu=True)
+            sink.add(enc.bn1.weight, dgamma)
+            sink.add(enc.bn1.bias, dbeta)
+            sink.add(enc.conv1.bias, colsum(draw, M, c0))
+            dw = _zeros(c0 * Cc, dg.device)
+            _ck(_lib().bevf_smallk_wgrad_f32(draw.data_ptr(), rows.data_ptr(), dw.data_ptr(), M, Cc, c0, _st()),
+                "bevf_smallk_wgrad_f32")
+            sink.add(enc.conv1.weight, dw[:c0 * Cc])
+
     # -- fusion + head -----------------------------------------------------------------------------------------------------------
     def forward(self, imgs, pts, radars):
         m = self.m
-        if m.use_radar and radars is not None:
-            raise NotImplementedError("training with the radar branch is not built yet (camera / lidar / camera+lidar are)")
         fus = m.fusion
         Sh, Sw, bc = fus.bev_h, fus.bev_w, fus.bev_channels
         P = Sh * Sw
         self.has_cam = m.use_camera and imgs is not None
         self.has_lid = m.use_lidar and pts is not None
-        nmod = int(self.has_cam) + int(self.has_lid)
+        self.has_rad = m.use_radar and radars is not None
+        nmod = int(self.has_cam) + int(self.has_lid) + int(self.has_rad)
         if nmod == 0:
             raise ValueError("No modality features provided")
-        dev = (imgs if self.has_cam else pts).device
-        cam_feat = lid_feat = None
+        dev = imgs.device if self.has_cam else (pts.device if self.has_lid else radars[0].device)
+        cam_feat = lid_feat = rad_feat = None
+        if self.has_rad:
+            rad_feat, B = self._radar_forward(radars)
         if self.has_cam:
             cam_feat, (B, ncam, Hc, Wc) = self._camera_forward(imgs)
         if self.has_lid:
             lid_feat = self._lidar_forward(pts)
             B = self.pn_geom[0]
         ccs = bc * nmod
+        if ccs != fus.bev_fusion[0].weight.shape[1]:
+            raise RuntimeError(f"expected input to have {fus.bev_fusion[0].weight.shape[1]} channels, but got {ccs} channels instead")
         concat = _new(B * P * ccs, dev)
         slot = 0
         self.B, self.ccs = B, ccs
@@ -464,6 +526,18 @@ class DetectorTape:
                 self.lid_resize = Bilinear()
                 self.lid_resize.forward(g3, B, s1, s1, bc, Sh, Sw, y=concat[slot * bc:], y_cs=ccs)
             self.lid_slot = slot
+            slot += 1
+        if self.has_rad:
+            self.rp = LinearLayer(fus.radar_proj[0], True)
+            rv = self.rp.forward(rad_feat, B)
+            r0 = _new(B * P * bc, dev)
+            L.broadcast_nhwc(rv, r0, B, P, bc, bc)
+            self.rr1 = ConvBNLayer(fus.radar_refine[0], fus.radar_refine[1], True)
+            self.rr2 = ConvBNLayer(fus.radar_refine[3], fus.radar_refine[4], True)
+            r1, _, _ = self.rr1.forward(r0, B, Sh, Sw)
+            r2, _, _ = self.rr2.forward(r1, B, Sh, Sw)
+            concat[:B * P * ccs].view(B * P, ccs)[:, slot * bc:(slot + 1) * bc] = r2[:B * P * bc].view(B * P, bc)   # slice copy
+            self.rad_slot = slot
             slot += 1
         self.f1 = ConvBNLayer(fus.bev_fusion[0], fus.bev_fusion[1], True)
         self.f2 = ConvBNLayer(fus.bev_fusion[3], fus.bev_fusion[4], True)
@@ -531,6 +605,14 @@ class DetectorTape:
         da1, _ = self.f2.backward(dfused, sink)
         dconcat, _ = self.f1.backward(da1, sink)
         bc = m.fusion.bev_channels
+        if self.has_rad:
+            ccs = self.ccs
+            dr2 = dconcat[:B * P * ccs].view(B * P, ccs)[:, self.rad_slot * bc:(self.rad_slot + 1) * bc].contiguous().view(-1)
+            dr1, _ = self.rr2.backward(dr2, sink)
+            dr0, _ = self.rr1.backward(dr1, sink)
+            drv = torch.cat([colsum(dr0[b * P * bc:], P, bc) for b in range(B)])      # d(broadcast) = sum over cells
+            drad = self.rp.backward(drv.contiguous(), sink)
+            self._radar_backward(drad, sink)
         if self.has_lid:
             dg3 = self.lid_resize.backward(dconcat[self.lid_slot * bc:])
             dg2, _ = self.lu2.backward(dg3, sink)
