@@ -33,6 +33,9 @@ CONFIGS = {
             modality="camera+lidar", cams=6, h=900, w=1600, points=35000, radars=0, bev=128),
     3: dict(name="camera+LiDAR+radar, 6x900x1600 + 35k points + 5x125 radar, BEV 128x128",
             modality="camera+lidar+radar", cams=6, h=900, w=1600, points=35000, radars=5, bev=128),
+    # config 4: the reference's training step (src/train_detect.py: images resized to 448x800, BEV 50x50 targets)
+    4: dict(name="train step camera+LiDAR, 6x448x800 + 35k points, BEV 50x50, 20 GT boxes/frame, AdamW + clip 10",
+            modality="camera+lidar", cams=6, h=448, w=800, points=35000, radars=0, bev=50),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
@@ -104,6 +107,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4, help="frames per step per GPU")
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="train = BASELINE config 4: fwd + targets + loss + bwd + grad all-reduce + clip + AdamW")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true", help="skip the per-launch HIP-event brackets")
     args = ap.parse_args()
@@ -113,6 +118,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = replicas.init("nccl", dev)              # RCCL; only for the barrier and the MAX of the elapsed time
+    if args.mode == "train":
+        args.config = 4
+        if args.batch == 4:
+            args.batch = 8                              # BASELINE config 4: per-GPU batch 8
     cfg = CONFIGS[args.config]
 
     model_cpu = build_model(cfg)
@@ -120,8 +129,28 @@ def main():
     model = model_cpu.to(dev)
     inputs = make_inputs(cfg, args.batch, replicas.frame_seed(0x5EED, args.config, rank), dev)
 
-    def step():
-        return model(*inputs)
+    if args.mode == "train":
+        from bevfusion_multimodal_3d_object_detection_amd import centernet_target as ct
+        from bevfusion_multimodal_3d_object_detection_amd import training
+        model.train()
+        boxes, labels = synth.gt_boxes(args.batch, 20, seed=replicas.frame_seed(0x5EED, args.config, rank))
+        gt = {"gt_boxes": boxes.to(dev), "gt_labels": labels.to(dev)}
+        crit = ct.CenterNetLoss()
+        opt = training.FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.01)     # ref train_detect.py:725-741
+
+        def step():
+            pred = model(*inputs)
+            tgt = ct.prepare_centernet_targets(gt, dev)
+            losses = crit(pred, tgt)
+            opt.zero_grad()
+            losses["total_loss"].backward()
+            replicas.allreduce_gradients(model.parameters(), dist)                    # RCCL, DP only
+            training.clip_grad_norm_(model.parameters(), 10.0)
+            opt.step()
+            return {k: v.detach() for k, v in losses.items()}
+    else:
+        def step():
+            return model(*inputs)
 
     for _ in range(max(args.warmup, 1)):
         out = step()
@@ -148,15 +177,26 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
-            "config": {"workload": cfg["name"], "batch_per_gpu": args.batch, "parallelism": f"replicas x{world}",
-                       "weights": "random-init (synthetic, seeded)", "mode": "inference forward -> 5 head tensors"},
+            "config": {"workload": cfg["name"], "batch_per_gpu": args.batch,
+                       "parallelism": f"replicas x{world}" if args.mode == "infer" else f"dp{world}",
+                       "weights": "random-init (synthetic, seeded)",
+                       "mode": "inference forward -> 5 head tensors" if args.mode == "infer"
+                       else "training step: fwd (train-mode BN) + targets + loss + bwd + grad all-reduce + clip + AdamW"},
         }
+        if args.mode == "train":
+            line["metric"] = "training frames/sec (camera+LiDAR, per-GPU batch 8)"
         if timer is not None:
             tot = timer.totals()
             conv = tot.get("conv_igemm_f32")
+            if conv and args.mode == "train":                          # forward + data-gradient + weight-gradient GEMMs
+                for extra in ("conv_dgrad_f32", "conv_wgrad_f32"):
+                    e = tot.get(extra)
+                    if e:
+                        conv = {k: conv[k] + e[k] for k in conv}
             if conv:
                 ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
-                line["roofline"] = {"kernel": "conv_igemm_f32", "bound": "mfma", "achieved": ach,
+                line["roofline"] = {"kernel": "conv_igemm_f32" if args.mode == "infer" else "conv_igemm_f32+conv_wgrad_f32",
+                                    "bound": "mfma", "achieved": ach,
                                     "traffic_source": None,
                                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
                                     "traffic": None, "launches_per_step": conv["launches"] / args.steps,
@@ -175,7 +215,7 @@ def main():
             stem = tot.get("stem_conv7x7_f32")
             if stem:
                 line["stem_tflops"] = stem["flops"] / (stem["ms"] * 1e-3) / 1e12
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.mode == "infer":
             line["cpu_baseline"] = cpu_baseline(cfg, state)
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)

@@ -52,3 +52,41 @@ def max_over_ranks(value: float, dist, device: torch.device) -> float:
 def aggregate_fps(frames_per_rank: int, world: int, elapsed_max_s: float) -> float:
     """Whole-job throughput: all ranks' frames over the slowest rank's time."""
     return world * frames_per_rank / elapsed_max_s
+
+
+# ---- data-parallel training (SURVEY.md 8e): one exchange step per iteration = all-reduce of the flat gradient ----------
+
+def allreduce_gradients(parameters, dist, bucket_bytes: int = 256 << 20) -> int:
+    """Average `p.grad` over the ranks: gradients are packed into flat buckets (a few large collectives, not 243
+    small ones), summed with one all-reduce each (RCCL over xGMI on the GPU node, gloo in the CPU tests) and
+    divided by the world size; BatchNorm buffers stay local (the reference has no SyncBN).  Returns the number of
+    collectives issued.  With dist None (single process) this is a no-op."""
+    if dist is None:
+        return 0
+    world = dist.get_world_size()
+    params = [p for p in parameters if p.grad is not None]
+    n_coll, bucket, size = 0, [], 0
+
+    def flush():
+        nonlocal n_coll, bucket, size
+        if not bucket:
+            return
+        flat = torch.cat([p.grad.detach().reshape(-1) for p in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(world)
+        o = 0
+        for p in bucket:
+            n = p.grad.numel()
+            p.grad.copy_(flat[o:o + n].view_as(p.grad))
+            o += n
+        n_coll += 1
+        bucket, size = [], 0
+
+    for p in params:
+        nbytes = p.grad.numel() * p.grad.element_size()
+        if bucket and size + nbytes > bucket_bytes:
+            flush()
+        bucket.append(p)
+        size += nbytes
+    flush()
+    return n_coll

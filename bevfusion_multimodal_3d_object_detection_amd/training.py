@@ -60,8 +60,9 @@ def _pixtab(N, H, W, k, stride, pad, dev) -> torch.Tensor:
 def conv_raw(x, w_ohwi, bias, N, H, W, cin, cout, k, stride, pad, relu=False):
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     y = _new(N * Ho * Wo * cout, x.device)
-    L.conv2d_nhwc(x, w_ohwi, None, bias, y, N=N, H=H, W=W, Cin=cin, x_cs=cin, Cout=cout, y_cs=cout, KH=k, KW=k,
-                  stride=stride, pad=pad, relu=relu)
+    with E._span("conv_igemm_f32", flops=2.0 * N * Ho * Wo * cout * k * k * cin):
+        L.conv2d_nhwc(x, w_ohwi, None, bias, y, N=N, H=H, W=W, Cin=cin, x_cs=cin, Cout=cout, y_cs=cout, KH=k, KW=k,
+                      stride=stride, pad=pad, relu=relu)
     return y, Ho, Wo
 
 
@@ -71,7 +72,9 @@ def conv_wgrad(x, dy, N, H, W, cin, cout, k, stride, pad, dw=None) -> torch.Tens
         dw = _zeros(cout * k * k * cin, x.device)
     d = L.WgradDesc(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _pixtab(N, H, W, k, stride, pad, x.device).data_ptr(),
                     N, H, W, cin, cin, cout, cout, k, k, stride, pad)
-    _ck(_lib().bevf_conv2d_wgrad_f32(C.byref(d), _st()), "bevf_conv2d_wgrad_f32")
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    with E._span("conv_wgrad_f32", flops=2.0 * N * Ho * Wo * cout * k * k * cin):
+        _ck(_lib().bevf_conv2d_wgrad_f32(C.byref(d), _st()), "bevf_conv2d_wgrad_f32")
     return dw[:cout * k * k * cin].view(cout, k, k, cin)
 
 
@@ -88,8 +91,9 @@ def conv_dgrad(dy, weight_oihw, N, H, W, cin, cout, k, stride, pad):
     else:
         assert (Ho, Wo) == (H, W), "stride-1 convs on this path keep the spatial size"
     dx = _new(N * H * W * cin, dy.device)
-    L.conv2d_nhwc(src, wt, None, None, dx, N=N, H=sh, W=sw, Cin=cout, x_cs=cout, Cout=cin, y_cs=cin, KH=k, KW=k,
-                  stride=1, pad=k - 1 - pad, relu=False)
+    with E._span("conv_dgrad_f32", flops=2.0 * N * Ho * Wo * cout * k * k * cin):     # algorithmic (no zero-stuffing waste)
+        L.conv2d_nhwc(src, wt, None, None, dx, N=N, H=sh, W=sw, Cin=cout, x_cs=cout, Cout=cin, y_cs=cin, KH=k, KW=k,
+                      stride=1, pad=k - 1 - pad, relu=False)
     return dx
 
 

@@ -47,7 +47,42 @@ def test_two_rank_replicas_gloo():
     assert replicas.aggregate_fps(40, 2, 2.0) == 40.0
 
 
+def _dp_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    dist = replicas.init("gloo")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 4))
+    x = torch.randn(8, 16, generator=torch.Generator().manual_seed(100 + rank))     # each rank its own shard
+    net(x).square().mean().backward()
+    local = [p.grad.clone() for p in net.parameters()]
+    n = replicas.allreduce_gradients(net.parameters(), dist, bucket_bytes=1024)     # small buckets: several collectives
+    q.put((rank, [g.numpy() for g in local], [p.grad.numpy().copy() for p in net.parameters()], n))
+    replicas.barrier(dist)
+    dist.destroy_process_group()
+
+
+def test_dp_gradient_allreduce_is_mean_of_rank_gradients():
+    """N-rank all-reduced grads == mean of the N single-rank grads (loss normalisers stay per shard)."""
+    import numpy as np
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, l0, r0, n0), (_, l1, r1, n1) = got
+    assert n0 == n1 and n0 >= 2
+    for a, b, ra, rb in zip(l0, l1, r0, r1):
+        assert np.allclose(ra, (a + b) / 2, rtol=1e-6, atol=1e-7) and np.array_equal(ra, rb)
+
+
 def test_single_process_is_a_noop():
+    assert replicas.allreduce_gradients([], None) == 0
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         os.environ.pop(k, None)
     assert replicas.init("gloo") is None
