@@ -65,14 +65,28 @@ __global__ __launch_bounds__(256) void stats_partials(const float* __restrict__ 
   }
 }
 
+// merge of the G per-workgroup partials of one channel: 8 lanes take g = lane, lane+8, ... (fixed order), then a
+// fixed-order sum of the 8 lane totals; 32 channels per workgroup
+__device__ __forceinline__ void merge_partials(const float* __restrict__ part, int C, int G, int c, int gl, double& s1,
+                                               double& s2) {
+  s1 = 0; s2 = 0;
+  if (c < C)
+    for (int g = gl; g < G; g += 8) { s1 += part[((size_t)g * C + c) * 2]; s2 += part[((size_t)g * C + c) * 2 + 1]; }
+#pragma unroll
+  for (int sft = 1; sft < 8; sft <<= 1) {                 // lanes of one channel are 8 consecutive threads
+    s1 += __shfl_xor(s1, sft);
+    s2 += __shfl_xor(s2, sft);
+  }
+}
+
 // mean, biased var, invstd from the partials (double, fixed order)
 __global__ __launch_bounds__(256) void stats_finalize(const float* __restrict__ x, const float* __restrict__ part,
                                                        float* __restrict__ mean, float* __restrict__ var,
                                                        float* __restrict__ invstd, int M, int C, int G, float eps) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0, s2 = 0;
-  for (int g = 0; g < G; ++g) { s1 += part[((size_t)g * C + c) * 2]; s2 += part[((size_t)g * C + c) * 2 + 1]; }
+  const int c = blockIdx.x * 32 + (threadIdx.x >> 3), gl = threadIdx.x & 7;
+  double s1, s2;
+  merge_partials(part, C, G, c, gl, s1, s2);
+  if (c >= C || gl != 0) return;
   const double sh = x[c], d = s1 / M;
   const double v = s2 / M - d * d;
   mean[c] = (float)(sh + d);
@@ -171,10 +185,10 @@ __global__ __launch_bounds__(256) void bn_bwd_partials(float* __restrict__ dy, c
 
 __global__ __launch_bounds__(256) void sums_finalize(const float* __restrict__ part, float* __restrict__ s_dy,
                                                       float* __restrict__ s_dyx, int C, int G) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0, s2 = 0;
-  for (int g = 0; g < G; ++g) { s1 += part[((size_t)g * C + c) * 2]; s2 += part[((size_t)g * C + c) * 2 + 1]; }
+  const int c = blockIdx.x * 32 + (threadIdx.x >> 3), gl = threadIdx.x & 7;
+  double s1, s2;
+  merge_partials(part, C, G, c, gl, s1, s2);
+  if (c >= C || gl != 0) return;
   s_dy[c] = (float)s1;
   if (s_dyx) s_dyx[c] = (float)s2;
 }
@@ -222,7 +236,7 @@ extern "C" int bevf_bn_stats_f32(const float* x, float* work, float* mean, float
   int G = (M + lanes - 1) / lanes;
   if (G > kStatGrid) G = kStatGrid;
   hipLaunchKernelGGL(stats_partials, dim3(G), dim3(256), 256 * 8 * sizeof(float), st, x, work, M, C, cs);
-  hipLaunchKernelGGL(stats_finalize, dim3((C + 255) / 256), dim3(256), 0, st, x, work, mean, var, invstd, M, C, G, eps);
+  hipLaunchKernelGGL(stats_finalize, dim3((C + 31) / 32), dim3(256), 0, st, x, work, mean, var, invstd, M, C, G, eps);
   return bevf_check_launch("bevf_bn_stats_f32");
 }
 
@@ -250,7 +264,7 @@ extern "C" int bevf_bn_backward_f32(float* dy, const float* y, const float* x, c
   if (G > kStatGrid) G = kStatGrid;
   hipLaunchKernelGGL(bn_bwd_partials, dim3(G), dim3(256), 256 * 8 * sizeof(float), st, dy, y, x, mean, invstd, work, M, C,
                      cs, relu);
-  hipLaunchKernelGGL(sums_finalize, dim3((C + 255) / 256), dim3(256), 0, st, work, dbeta, dgamma, C, G);
+  hipLaunchKernelGGL(sums_finalize, dim3((C + 31) / 32), dim3(256), 0, st, work, dbeta, dgamma, C, G);
   if (dx)
     hipLaunchKernelGGL(bn_bwd_apply, dim3(ew_grid((long long)M * (C / 4))), dim3(256), 0, st, dy, x, mean, invstd, gamma,
                        dbeta, dgamma, dx, (long long)M, C, cs);

@@ -33,50 +33,59 @@ __global__ __launch_bounds__(256) void relu_mask(float* __restrict__ dy, const f
 __global__ __launch_bounds__(256) void maxpool_fwd_idx(const float* __restrict__ x, float* __restrict__ y,
                                                         unsigned char* __restrict__ idx, int N, int H, int W, int C, int Ho,
                                                         int Wo) {
-  const long long total = (long long)N * Ho * Wo * C;
+  const int c4 = C >> 2;
+  const long long total = (long long)N * Ho * Wo * c4;
   GRID_STRIDE(i, total) {
-    const int c = (int)(i % C);
-    long long pix = i / C;
+    const int c = (int)(i % c4) * 4;
+    long long pix = i / c4;
     const int ow = (int)(pix % Wo);
     pix /= Wo;
     const int oh = (int)(pix % Ho), n = (int)(pix / Ho);
-    float m = -INFINITY;
-    int best = 0;
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int best[4] = {0, 0, 0, 0};
     for (int dh = 0; dh < 3; ++dh) {
       const int ih = 2 * oh - 1 + dh;
       if ((unsigned)ih >= (unsigned)H) continue;
       for (int dw = 0; dw < 3; ++dw) {
         const int iw = 2 * ow - 1 + dw;
         if ((unsigned)iw >= (unsigned)W) continue;
-        const float v = x[((size_t)(n * H + ih) * W + iw) * C + c];
-        if (v > m || (v != v)) { m = v; best = dh * 3 + dw; }
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((size_t)(n * H + ih) * W + iw) * C + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (v[j] > m[j] || (v[j] != v[j])) { m[j] = v[j]; best[j] = dh * 3 + dw; }
       }
     }
-    y[i] = m;
-    idx[i] = (unsigned char)best;
+    *reinterpret_cast<f32x4*>(y + (size_t)i * 4) = m;
+    *reinterpret_cast<unsigned*>(idx + (size_t)i * 4) =
+        (unsigned)best[0] | ((unsigned)best[1] << 8) | ((unsigned)best[2] << 16) | ((unsigned)best[3] << 24);
   }
 }
 __global__ __launch_bounds__(256) void maxpool_bwd(const float* __restrict__ dy, const unsigned char* __restrict__ idx,
                                                     float* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo) {
-  const long long total = (long long)N * H * W * C;
+  const int c4 = C >> 2;
+  const long long total = (long long)N * H * W * c4;
   GRID_STRIDE(i, total) {                              // gather: every output window that contains this input pixel
-    const int c = (int)(i % C);
-    long long pix = i / C;
+    const int c = (int)(i % c4) * 4;
+    long long pix = i / c4;
     const int iw = (int)(pix % W);
     pix /= W;
     const int ih = (int)(pix % H), n = (int)(pix / H);
-    float g = 0.f;
-    for (int oh = (ih + 1 - 2 + 1) / 2; oh <= (ih + 1) / 2; ++oh) {          // 2*oh-1 <= ih <= 2*oh+1
-      if (oh < 0 || oh >= Ho) continue;
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    for (int oh = ih / 2; oh <= (ih + 1) / 2; ++oh) {                          // 2*oh-1 <= ih <= 2*oh+1
+      if (oh >= Ho) continue;
       const int dh = ih - (2 * oh - 1);
-      for (int ow = (iw + 1 - 2 + 1) / 2; ow <= (iw + 1) / 2; ++ow) {
-        if (ow < 0 || ow >= Wo) continue;
-        const int dw = iw - (2 * ow - 1);
+      for (int ow = iw / 2; ow <= (iw + 1) / 2; ++ow) {
+        if (ow >= Wo) continue;
+        const unsigned code = (unsigned)(dh * 3 + (iw - (2 * ow - 1)));
         const size_t o = ((size_t)(n * Ho + oh) * Wo + ow) * C + c;
-        if (idx[o] == dh * 3 + dw) g += dy[o];
+        const unsigned id4 = *reinterpret_cast<const unsigned*>(idx + o);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (((id4 >> (8 * j)) & 0xff) == code) g[j] += d[j];
       }
     }
-    dx[i] = g;
+    *reinterpret_cast<f32x4*>(dx + (size_t)i * 4) = g;
   }
 }
 
@@ -125,17 +134,41 @@ __global__ __launch_bounds__(256) void cam_mean_bwd(const f32x4* __restrict__ dy
 }
 
 // ---- group max with argmax, and its scatter backward (dx zero-filled by the caller) -----------------------------------
-__global__ __launch_bounds__(256) void group_max_idx(const float* __restrict__ x, float* __restrict__ y,
-                                                      int* __restrict__ idx, int P, int C, long long total) {
+// stage 1: one workgroup per (group, chunk of GM_CHUNK points): threads own channel quads, rows are read coalesced
+constexpr int GM_CHUNK = 128;
+__global__ __launch_bounds__(256) void group_max_partial(const float* __restrict__ x, float* __restrict__ pmax,
+                                                          int* __restrict__ pidx, int P, int C, int nchunks) {
+  const int g = blockIdx.x / nchunks, ch = blockIdx.x - g * nchunks;
+  const int p0 = ch * GM_CHUNK, p1 = (p0 + GM_CHUNK < P) ? p0 + GM_CHUNK : P;
+  const int c4 = C >> 2;
+  for (int cq = threadIdx.x; cq < c4; cq += 256) {
+    const float* src = x + ((size_t)g * P + p0) * C + cq * 4;
+    f32x4 m = *reinterpret_cast<const f32x4*>(src);
+    int bi[4] = {p0, p0, p0, p0};
+    for (int p = p0 + 1; p < p1; ++p) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)(p - p0) * C);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (v[j] > m[j]) { m[j] = v[j]; bi[j] = p; }
+    }
+    const size_t o = ((size_t)g * nchunks + ch) * C + cq * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { pmax[o + j] = m[j]; pidx[o + j] = bi[j]; }
+  }
+}
+// stage 2: first maximum over the chunks (chunk order = point order, strict > keeps the earliest)
+__global__ __launch_bounds__(256) void group_max_final(const float* __restrict__ pmax, const int* __restrict__ pidx,
+                                                        float* __restrict__ y, int* __restrict__ idx, int C, int nchunks,
+                                                        long long total) {
   GRID_STRIDE(i, total) {
     const long long g = i / C;
     const int c = (int)(i - g * C);
-    const float* src = x + (size_t)g * P * C + c;
-    float m = src[0];
-    int best = 0;
-    for (int p = 1; p < P; ++p) {
-      const float v = src[(size_t)p * C];
-      if (v > m) { m = v; best = p; }
+    const size_t base = (size_t)g * nchunks * C + c;
+    float m = pmax[base];
+    int best = pidx[base];
+    for (int k = 1; k < nchunks; ++k) {
+      const float v = pmax[base + (size_t)k * C];
+      if (v > m) { m = v; best = pidx[base + (size_t)k * C]; }
     }
     y[i] = m;
     idx[i] = best;
@@ -173,15 +206,30 @@ __global__ __launch_bounds__(256) void zero_stuff(const float* __restrict__ dy, 
 __global__ __launch_bounds__(256) void linear_bwd_dx_partials(const float* __restrict__ dy, const float* __restrict__ w,
                                                                float* __restrict__ part, int B, int K, int O, int chunk,
                                                                int perm_inner, int perm_outer) {
+  extern __shared__ float sdy[];                          // [chunk][B] gradients of this workgroup's outputs
   const int o0 = blockIdx.x * chunk, o1 = (o0 + chunk < O) ? o0 + chunk : O;
+  for (int i = threadIdx.x; i < (o1 - o0) * B; i += 256) {
+    const int o = o0 + i / B, b = i - (i / B) * B;
+    const int oo = perm_inner > 0 ? (o % perm_inner) * perm_outer + o / perm_inner : o;
+    sdy[i] = dy[(size_t)b * O + oo];
+  }
+  __syncthreads();
   for (int k = threadIdx.x; k < K; k += 256) {
-    for (int b = 0; b < B; ++b) {
-      float acc = 0.f;
+    float acc[8];
+    for (int b0 = 0; b0 < B; b0 += 8) {
+      const int nb = B - b0 < 8 ? B - b0 : 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
       for (int o = o0; o < o1; ++o) {
-        const int oo = perm_inner > 0 ? (o % perm_inner) * perm_outer + o / perm_inner : o;
-        acc = fmaf(dy[(size_t)b * O + oo], w[(size_t)o * K + k], acc);
+        const float wv = w[(size_t)o * K + k];
+        const float* g = sdy + (o - o0) * B + b0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < nb) acc[j] = fmaf(g[j], wv, acc[j]);
       }
-      part[((size_t)blockIdx.x * B + b) * K + k] = acc;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < nb) part[((size_t)blockIdx.x * B + b0 + j) * K + k] = acc[j];
     }
   }
 }
@@ -420,16 +468,16 @@ extern "C" int bevf_relu_mask_f32(float* dy, const float* y, size_t n, void* str
   return bevf_check_launch("bevf_relu_mask_f32");
 }
 extern "C" int bevf_maxpool3x3s2_idx_f32(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C, void* stream) {
-  BEVF_REQUIRE(x && y && idx && N > 0 && H > 0 && W > 0 && C > 0, "maxpool_idx: bad arguments");
+  BEVF_REQUIRE(x && y && idx && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "maxpool_idx: bad arguments (C %% 4)");
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  hipLaunchKernelGGL(maxpool_fwd_idx, dim3(ew_grid((long long)N * Ho * Wo * C)), dim3(256), 0, ST, x, y, idx, N, H, W, C, Ho, Wo);
+  hipLaunchKernelGGL(maxpool_fwd_idx, dim3(ew_grid((long long)N * Ho * Wo * (C / 4))), dim3(256), 0, ST, x, y, idx, N, H, W, C, Ho, Wo);
   return bevf_check_launch("bevf_maxpool3x3s2_idx_f32");
 }
 extern "C" int bevf_maxpool3x3s2_bwd_f32(const float* dy, const uint8_t* idx, float* dx, int N, int H, int W, int C,
                                          void* stream) {
-  BEVF_REQUIRE(dy && idx && dx && N > 0 && H > 0 && W > 0 && C > 0, "maxpool_bwd: bad arguments");
+  BEVF_REQUIRE(dy && idx && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "maxpool_bwd: bad arguments (C %% 4)");
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  hipLaunchKernelGGL(maxpool_bwd, dim3(ew_grid((long long)N * H * W * C)), dim3(256), 0, ST, dy, idx, dx, N, H, W, C, Ho, Wo);
+  hipLaunchKernelGGL(maxpool_bwd, dim3(ew_grid((long long)N * H * W * (C / 4))), dim3(256), 0, ST, dy, idx, dx, N, H, W, C, Ho, Wo);
   return bevf_check_launch("bevf_maxpool3x3s2_bwd_f32");
 }
 extern "C" int bevf_bilinear_bwd_nhwc_f32(const float* dy, float* dx, int B, int Hi, int Wi, int C, int x_cs, int Ho,
@@ -447,10 +495,19 @@ extern "C" int bevf_cam_mean_bwd_f32(const float* dy, float* dx, int B, int ncam
                      reinterpret_cast<f32x4*>(dx), ncam, pc4, total);
   return bevf_check_launch("bevf_cam_mean_bwd_f32");
 }
-extern "C" int bevf_group_max_idx_f32(const float* x, float* y, int32_t* idx, int G, int P, int C, void* stream) {
-  BEVF_REQUIRE(x && y && idx && G > 0 && P > 0 && C > 0, "group_max_idx: bad arguments");
+extern "C" size_t bevf_group_max_idx_work_bytes(int G, int P, int C) {
+  return (size_t)G * ((P + GM_CHUNK - 1) / GM_CHUNK) * C * 8;
+}
+extern "C" int bevf_group_max_idx_f32(const float* x, float* y, int32_t* idx, void* work, int G, int P, int C,
+                                      void* stream) {
+  BEVF_REQUIRE(x && y && idx && work && G > 0 && P > 0 && C > 0 && C % 4 == 0, "group_max_idx: bad arguments");
+  BEVF_REQUIRE(bevf_aligned16(x), "group_max_idx: unaligned");
+  const int nchunks = (P + GM_CHUNK - 1) / GM_CHUNK;
+  float* pmax = static_cast<float*>(work);
+  int* pidx = reinterpret_cast<int*>(pmax + (size_t)G * nchunks * C);
+  hipLaunchKernelGGL(group_max_partial, dim3(G * nchunks), dim3(256), 0, ST, x, pmax, pidx, P, C, nchunks);
   const long long total = (long long)G * C;
-  hipLaunchKernelGGL(group_max_idx, dim3(ew_grid(total)), dim3(256), 0, ST, x, y, idx, P, C, total);
+  hipLaunchKernelGGL(group_max_final, dim3(ew_grid(total)), dim3(256), 0, ST, pmax, pidx, y, idx, C, nchunks, total);
   return bevf_check_launch("bevf_group_max_idx_f32");
 }
 extern "C" int bevf_group_max_bwd_f32(const float* dy, const int32_t* idx, float* dx, int G, int P, int C, void* stream) {
@@ -468,13 +525,13 @@ extern "C" int bevf_zero_stuff_nhwc_f32(const float* dy, float* out, int N, int 
 extern "C" size_t bevf_linear_bwd_work_floats(int B, int K, int O) { return (size_t)((O + 255) / 256 > 1024 ? 1024 : (O + 255) / 256) * B * K; }
 extern "C" int bevf_linear_bwd_f32(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db,
                                    float* work, int B, int K, int O, int perm_inner, int perm_outer, void* stream) {
-  BEVF_REQUIRE(dy && x && w && dw && work && B > 0 && K > 0 && K % 4 == 0 && O > 0, "linear_bwd: bad arguments");
+  BEVF_REQUIRE(dy && x && w && dw && work && B > 0 && B <= 64 && K > 0 && K % 4 == 0 && O > 0, "linear_bwd: bad arguments (B <= 64)");
   int G = (O + 255) / 256;
   if (G > 1024) G = 1024;
   const int chunk = (O + G - 1) / G;
   G = (O + chunk - 1) / chunk;
   if (dx) {
-    hipLaunchKernelGGL(linear_bwd_dx_partials, dim3(G), dim3(256), 0, ST, dy, w, work, B, K, O, chunk, perm_inner, perm_outer);
+    hipLaunchKernelGGL(linear_bwd_dx_partials, dim3(G), dim3(256), (size_t)chunk * B * sizeof(float), ST, dy, w, work, B, K, O, chunk, perm_inner, perm_outer);
     hipLaunchKernelGGL(linear_bwd_dx_final, dim3((B * K + 255) / 256), dim3(256), 0, ST, work, dx, B * K, G);
   }
   hipLaunchKernelGGL(linear_bwd_dw, dim3(ew_grid((long long)O * (K / 4))), dim3(256), 0, ST, dy, x, dw, db, B, K, O, perm_inner, perm_outer);

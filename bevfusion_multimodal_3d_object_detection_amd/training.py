@@ -380,8 +380,9 @@ class DetectorTape:
         feat = lyr.cout
         g = _new(B * feat, dev)
         self.pn_idx = torch.empty(B * feat, dtype=torch.int32, device=dev)
-        _ck(_lib().bevf_group_max_idx_f32(a.data_ptr(), g.data_ptr(), self.pn_idx.data_ptr(), B, Np, feat, _st()),
-            "bevf_group_max_idx_f32")
+        gwork = torch.empty(_lib().bevf_group_max_idx_work_bytes(B, Np, feat), dtype=torch.uint8, device=dev)
+        _ck(_lib().bevf_group_max_idx_f32(a.data_ptr(), g.data_ptr(), self.pn_idx.data_ptr(), gwork.data_ptr(), B, Np, feat,
+                                          _st()), "bevf_group_max_idx_f32")
         return g
 
     def _lidar_backward(self, dg, sink):
@@ -429,8 +430,9 @@ class DetectorTape:
             feat = layers[-1].cout
             g = _new(B * feat, rows.device)
             idx = torch.empty(B * feat, dtype=torch.int32, device=rows.device)
-            _ck(_lib().bevf_group_max_idx_f32(a.data_ptr(), g.data_ptr(), idx.data_ptr(), B, Np, feat, _st()),
-                "bevf_group_max_idx_f32")
+            gwork = torch.empty(_lib().bevf_group_max_idx_work_bytes(B, Np, feat), dtype=torch.uint8, device=rows.device)
+            _ck(_lib().bevf_group_max_idx_f32(a.data_ptr(), g.data_ptr(), idx.data_ptr(), gwork.data_ptr(), B, Np, feat,
+                                              _st()), "bevf_group_max_idx_f32")
             feats.append(g[:B * feat].view(B, feat))
             self.rad_sweeps.append((rows, bn0, layers, idx, (B, Np, Cc, c0, feat)))
         per = torch.stack(feats, dim=1).contiguous()                      # (B, R, feat) -- layout copy only

@@ -263,7 +263,8 @@ int bevf_maxpool3x3s2_bwd_f32(const float* dy, const uint8_t* idx, float* dx, in
 int bevf_bilinear_bwd_nhwc_f32(const float* dy, float* dx, int B, int Hi, int Wi, int C, int x_cs, int Ho, int Wo,
                                int y_cs, void* stream);                                 /* dx zero-filled    */
 int bevf_cam_mean_bwd_f32(const float* dy, float* dx, int B, int ncam, int P, int C, void* stream);
-int bevf_group_max_idx_f32(const float* x, float* y, int32_t* idx, int G, int P, int C, void* stream);
+size_t bevf_group_max_idx_work_bytes(int G, int P, int C);
+int bevf_group_max_idx_f32(const float* x, float* y, int32_t* idx, void* work, int G, int P, int C, void* stream);
 int bevf_group_max_bwd_f32(const float* dy, const int32_t* idx, float* dx, int G, int P, int C, void* stream); /* dx zero-filled */
 size_t bevf_linear_bwd_work_floats(int B, int K, int O);
 int bevf_linear_bwd_f32(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, float* work,
