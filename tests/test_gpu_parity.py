@@ -291,10 +291,11 @@ def test_lidar_resize_extension_128(gpu):
         assert rel_err(out[k].cpu(), ref[k]) <= MTOL, k
 
 
-def test_train_mode_is_refused(gpu):
-    m = fusion.create_detector("camera_only", "bev", "centernet", bev_h=8, bev_w=8).cuda().train()
+def test_standalone_modules_refuse_train_mode(gpu):
+    """Train-mode BatchNorm is built for the detector (training.py); a stand-alone encoder still needs eval()."""
+    m = encoders.ResNetCameraEncoder(backbone="resnet18", pretrained=False).cuda().train()
     with pytest.raises(NotImplementedError, match="eval"):
-        m(torch.zeros(1, 1, 3, 32, 32, device=gpu), None, None)
+        m(torch.zeros(1, 3, 32, 32, device=gpu))
 
 
 def test_no_modality_raises(gpu):
