@@ -20,6 +20,7 @@
 // CUs as the big ones drain.
 #include "common.h"
 
+#include <cmath>
 #include <type_traits>
 
 namespace {
@@ -390,21 +391,27 @@ extern "C" int bevf_conv2d_nhwc_f32(const bevf_conv_desc* d, void* stream) {
     case 6: return launch_hybrid<256, 64, 64, 64>(a, (int)(M / 256) / 2, st);
     default: bevf_set_error("conv: unknown tile variant %d", d->tile); return BEVF_ERR_ARG;
   }
-  // auto: big tiles for whole rounds of the chip, 64x64 tiles for the remaining rows
-  if (d->Cout <= 64) {
-    const int big = split_big_mtiles(M, 256, 1);
-    if (big == 0) return launch<64, 64, 32, 32>(a, st);
-    if (big == (int)((M + 255) / 256)) return launch<256, 64, 64, 64>(a, st);
-    return launch_hybrid<256, 64, 64, 64>(a, big, st);
-  }
-  // a ragged last 128-wide N tile would waste MFMA work (Cout = 320: 17 %): use 64-wide tiles there
-  if (d->Cout % 128 != 0 && (d->Cout % 128) <= 64) {
-    const long long ws = ((M + 127) / 128) * ((d->Cout + 63) / 64);
-    return ws >= 384 ? launch<128, 64, 64, 32>(a, st) : launch<64, 64, 32, 32>(a, st);
-  }
+  // auto: a small cost model over the tile shapes.  A CU runs `per_cu` workgroups of a shape at once (LDS-bound),
+  // they share its MFMA pipes, so a round of the chip costs area * per_cu / eff and a launch costs
+  // ceil(workgroups / (256 * per_cu)) rounds (measured with tools/conv_bench.py: 128x64 and 64x64 tiles at 3 and
+  // 5 workgroups per CU beat 128x128 at 2 per CU on everything but the longest-K layers).
+  auto wgs = [&](int bm, int bn) { return (double)((M + bm - 1) / bm) * ((d->Cout + bn - 1) / bn); };
+  auto rounds = [](double n, int per_cu) { return std::ceil(n / (256.0 * per_cu)); };
+  const double c64 = rounds(wgs(64, 64), 5) * 64 * 64 * 5 / 0.95;
+  const double c128x64 = rounds(wgs(128, 64), 3) * 128 * 64 * 3 / 0.98;
+  double c128 = 1e300;
+  int big = 0;
   const int tn = (d->Cout + 127) / 128;
-  const int big = split_big_mtiles(M, 128, tn);
-  if (big == 0) return launch<64, 64, 32, 32>(a, st);
-  if (big == (int)((M + 127) / 128)) return launch<128, 128, 64, 64>(a, st);
-  return launch_hybrid<128, 128, 64, 64>(a, big, st);
+  if (d->Cout > 64) {
+    big = split_big_mtiles(M, 128, tn);
+    const long long tail_rows = M - (long long)big * 128;
+    const double tail = tail_rows > 0 ? rounds((double)((tail_rows + 63) / 64) * ((d->Cout + 63) / 64), 5) * 64 * 64 * 5 / 0.95 : 0.0;
+    c128 = big > 0 ? rounds((double)big * tn, 2) * 128 * 128 * 2 + tail : 1e300;
+  }
+  if (c128 <= c128x64 && c128 <= c64) {
+    if (big == (int)((M + 127) / 128)) return launch<128, 128, 64, 64>(a, st);
+    return launch_hybrid<128, 128, 64, 64>(a, big, st);
+  }
+  if (c128x64 <= c64) return launch<128, 64, 64, 32>(a, st);
+  return launch<64, 64, 32, 32>(a, st);
 }

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of bevf_conv2d_nhwc_f32 tile variants on the ResNet / fusion layer shapes (A/B in one process)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bevfusion_multimodal_3d_object_detection_amd import _lib as L
+
+SHAPES = {  # name: (N, H, W, Cin, Cout, k, stride, pad)
+    "layer1": (24, 225, 400, 64, 64, 3, 1, 1),
+    "layer2": (24, 113, 200, 128, 128, 3, 1, 1),
+    "layer3": (24, 57, 100, 256, 256, 3, 1, 1),
+    "proj": (24, 57, 100, 256, 512, 1, 1, 0),
+    "fusion1": (4, 128, 128, 512, 512, 3, 1, 1),
+    "head": (4, 128, 128, 256, 320, 3, 1, 1),
+    "layer1_b1": (6, 225, 400, 64, 64, 3, 1, 1),
+    "layer3_b1": (6, 57, 100, 256, 256, 3, 1, 1),
+}
+dev = torch.device("cuda")
+names = sys.argv[1].split(",") if len(sys.argv) > 1 else list(SHAPES)
+tiles = [int(t) for t in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1, 2, 3, 4]
+for name in names:
+    N, H, W, Cin, Cout, k, s, p = SHAPES[name]
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    x = torch.randn(N * H * W * Cin, device=dev)
+    w = torch.randn(Cout * k * k * Cin, device=dev) * 0.05
+    sc, sh = torch.rand(Cout, device=dev) + 0.5, torch.randn(Cout, device=dev)
+    y = torch.empty(N * Ho * Wo * Cout, device=dev)
+    flops = 2.0 * N * Ho * Wo * Cout * k * k * Cin
+    res = []
+    for t in tiles:
+        try:
+            for _ in range(2):
+                L.conv2d_nhwc(x, w, sc, sh, y, N=N, H=H, W=W, Cin=Cin, x_cs=Cin, Cout=Cout, y_cs=Cout, KH=k, KW=k, stride=s, pad=p, relu=True, tile=t)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                L.conv2d_nhwc(x, w, sc, sh, y, N=N, H=H, W=W, Cin=Cin, x_cs=Cin, Cout=Cout, y_cs=Cout, KH=k, KW=k, stride=s, pad=p, relu=True, tile=t)
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            res.append(f"tile{t}: {ms*1e3:7.1f}us {flops/ms/1e9:6.1f}TF")
+        except Exception as ex:
+            res.append(f"tile{t}: ERR {str(ex)[:40]}")
+    print(f"{name:10s} {flops/1e9:7.1f}GF  " + "  ".join(res))
