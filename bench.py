@@ -38,6 +38,7 @@ CONFIGS = {
             modality="camera+lidar", cams=6, h=448, w=800, points=35000, radars=0, bev=50),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
 
 
@@ -109,6 +110,8 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="train = BASELINE config 4: fwd + targets + loss + bwd + grad all-reduce + clip + AdamW")
+    ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32",
+                    help="storage dtype of weights/activations (bf16 = BASELINE configs 3/5: bf16 storage, fp32 accumulate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true", help="skip the per-launch HIP-event brackets")
     args = ap.parse_args()
@@ -127,6 +130,10 @@ def main():
     model_cpu = build_model(cfg)
     state = {k: v.clone() for k, v in model_cpu.state_dict().items()}
     model = model_cpu.to(dev)
+    if args.dtype == "bf16":
+        if args.mode == "train":
+            raise SystemExit("training runs in fp32 (the reference has no mixed precision, SURVEY.md 5)")
+        model = model.bfloat16()
     inputs = make_inputs(cfg, args.batch, replicas.frame_seed(0x5EED, args.config, rank), dev)
 
     if args.mode == "train":
@@ -176,7 +183,7 @@ def main():
             "value": replicas.aggregate_fps(args.batch * args.steps, world, elapsed), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": cfg["name"], "batch_per_gpu": args.batch,
                        "parallelism": f"replicas x{world}" if args.mode == "infer" else f"dp{world}",
                        "weights": "random-init (synthetic, seeded)",
@@ -195,15 +202,16 @@ def main():
                         conv = {k: conv[k] + e[k] for k in conv}
             if conv:
                 ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
+                peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "fp32" else PEAK_BF16_MFMA_TFLOPS
                 line["roofline"] = {"kernel": "conv_igemm_f32" if args.mode == "infer" else "conv_igemm_f32+conv_wgrad_f32",
                                     "bound": "mfma", "achieved": ach,
                                     "traffic_source": None,
-                                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                                    "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                     "traffic": None, "launches_per_step": conv["launches"] / args.steps,
                                     "avg_launch_ms": conv["ms"] / conv["launches"],
                                     "gflop_per_step": conv["flops"] / args.steps / 1e9,
                                     "share_of_step": conv["ms"] / (1e3 * elapsed)}
-                tr = pmc_traffic(args.config, args.batch)
+                tr = pmc_traffic(args.config, args.batch) if args.dtype == "fp32" and args.mode == "infer" else None
                 if tr is not None:
                     line["roofline"]["traffic"], line["roofline"]["traffic_source"] = tr
             pool = tot.get("bev_pool")

@@ -100,6 +100,17 @@ SIGNATURES = {
     "bevf_nms_keep_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 3 + [C.c_void_p]),
     "bevf_centernet_loss_work_floats": (C.c_size_t, []),
     "bevf_centernet_loss_f32": (C.c_int, [C.POINTER(LossDesc), C.c_void_p]),
+    # ---- bf16 storage path ----
+    "bevf_conv2d_nhwc_bf16": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "bevf_stem_conv7x7_bf16out": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
+    "bevf_maxpool3x3s2_nhwc_bf16": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
+    "bevf_pointwise_smallk_bf16out": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
+    "bevf_linear_bf16w": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 7 + [C.c_void_p]),
+    "bevf_cam_mean_bf16": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
+    "bevf_bilinear_nhwc_bf16": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 8 + [C.c_void_p]),
+    "bevf_broadcast_nhwc_bf16": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
+    "bevf_expand_border_classes_bf16": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 5 + [C.c_void_p]),
+    "bevf_head_tail_bf16": (C.c_int, [C.POINTER(HeadDesc), C.c_void_p]),
     # ---- training step ----
     "bevf_conv_pixtab": (C.c_int, [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]),
     "bevf_conv2d_wgrad_f32": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
@@ -161,6 +172,18 @@ def _p(t: Optional[torch.Tensor], dtype=torch.float32) -> Optional[int]:
     return t.data_ptr()
 
 
+BF16 = torch.bfloat16
+
+
+def _sfx(t: torch.Tensor) -> str:
+    """Entry-point suffix for a storage dtype."""
+    if t.dtype == torch.float32:
+        return "f32"
+    if t.dtype == BF16:
+        return "bf16"
+    raise BevfError(f"unsupported storage dtype {t.dtype} (fp32 or bf16)")
+
+
 def _pc(t: Optional[torch.Tensor], dtype=torch.float32) -> Optional[int]:
     if t is not None and not t.is_contiguous():
         raise BevfError("tensor must be contiguous")
@@ -189,9 +212,11 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, scale, shift, y: Optional[torc
             raise BevfError("conv: scale/shift length != Cout")
     if colmax is not None and colmax.numel() < -(-M // rows_per_group) * Cout:
         raise BevfError("conv: colmax buffer too small")
-    d = ConvDesc(_p(x), _pc(w), _pc(scale), _pc(shift), _p(res), _p(y), _pc(colmax, torch.int32),
+    dt = x.dtype
+    d = ConvDesc(_p(x, dt), _pc(w, dt), _pc(scale), _pc(shift), _p(res, dt), _p(y, dt), _pc(colmax, torch.int32),
                  N, H, W, Cin, x_cs, Ho, Wo, Cout, y_cs, res_cs, KH, KW, stride, pad, int(relu), rows_per_group, tile)
-    _check(lib().bevf_conv2d_nhwc_f32(C.byref(d), _stream()), "bevf_conv2d_nhwc_f32")
+    fn = "bevf_conv2d_nhwc_" + _sfx(x)
+    _check(getattr(lib(), fn)(C.byref(d), _stream()), fn)
 
 
 def stem_conv7x7(x: torch.Tensor, w_packed: torch.Tensor, scale, shift, y: torch.Tensor, N: int, H: int, W: int,
@@ -199,22 +224,23 @@ def stem_conv7x7(x: torch.Tensor, w_packed: torch.Tensor, scale, shift, y: torch
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     if x.numel() != N * 3 * H * W or w_packed.numel() != 148 * 64 or y.numel() < N * Ho * Wo * 64:
         raise BevfError("stem: buffer sizes do not match N,H,W")
-    _check(lib().bevf_stem_conv7x7_f32(_pc(x), _pc(w_packed), _pc(scale), _pc(shift), _p(y), N, H, W, int(relu), _stream()),
-           "bevf_stem_conv7x7_f32")
+    fn = "bevf_stem_conv7x7_f32" if y.dtype == torch.float32 else "bevf_stem_conv7x7_bf16out"
+    _check(getattr(lib(), fn)(_pc(x), _pc(w_packed), _pc(scale), _pc(shift), _p(y, y.dtype), N, H, W, int(relu), _stream()), fn)
 
 
 def maxpool3x3s2(x: torch.Tensor, y: torch.Tensor, N: int, H: int, W: int, Cc: int):
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     if x.numel() < N * H * W * Cc or y.numel() < N * Ho * Wo * Cc:
         raise BevfError("maxpool: buffer too small")
-    _check(lib().bevf_maxpool3x3s2_nhwc_f32(_p(x), _p(y), N, H, W, Cc, _stream()), "bevf_maxpool3x3s2_nhwc_f32")
+    fn = "bevf_maxpool3x3s2_nhwc_" + _sfx(x)
+    _check(getattr(lib(), fn)(_p(x, x.dtype), _p(y, x.dtype), N, H, W, Cc, _stream()), fn)
 
 
 def pointwise_smallk(x, w, scale, shift, y, M: int, K: int, Cout: int, relu: bool):
     if x.numel() < M * K or w.numel() != Cout * K or y.numel() < M * Cout:
         raise BevfError("pointwise: buffer sizes do not match M,K,Cout")
-    _check(lib().bevf_pointwise_smallk_f32(_pc(x), _pc(w), _pc(scale), _pc(shift), _p(y), M, K, Cout, int(relu),
-                                           _stream()), "bevf_pointwise_smallk_f32")
+    fn = "bevf_pointwise_smallk_f32" if y.dtype == torch.float32 else "bevf_pointwise_smallk_bf16out"
+    _check(getattr(lib(), fn)(_pc(x), _pc(w), _pc(scale), _pc(shift), _p(y, y.dtype), M, K, Cout, int(relu), _stream()), fn)
 
 
 def group_max(x, y, G: int, P: int, Cc: int):
@@ -242,46 +268,53 @@ def radar_mlp_max(x, ws: Sequence[torch.Tensor], scales, shifts, out, R: int, B:
 def linear(x, w, bias, y, B: int, K: int, O: int, relu: bool, perm_inner: int = 0, perm_outer: int = 0):
     if x.numel() < B * K or w.numel() != O * K or y.numel() < B * O or (bias is not None and bias.numel() != O):
         raise BevfError("linear: buffer sizes do not match B,K,O")
-    _check(lib().bevf_linear_f32(_p(x), _pc(w), _pc(bias), _p(y), B, K, O, int(relu), perm_inner, perm_outer,
-                                 _stream()), "bevf_linear_f32")
+    if w.dtype == torch.float32:
+        _check(lib().bevf_linear_f32(_p(x), _pc(w), _pc(bias), _p(y), B, K, O, int(relu), perm_inner, perm_outer,
+                                     _stream()), "bevf_linear_f32")
+    else:
+        _check(lib().bevf_linear_bf16w(_p(x), _pc(w, BF16), _pc(bias), _p(y, y.dtype), int(y.dtype == BF16), B, K, O,
+                                       int(relu), perm_inner, perm_outer, _stream()), "bevf_linear_bf16w")
 
 
 def cam_mean(x, y, B: int, ncam: int, P: int, Cc: int):
     if x.numel() < B * ncam * P * Cc or y.numel() < B * P * Cc:
         raise BevfError("cam_mean: buffer too small")
-    _check(lib().bevf_cam_mean_f32(_p(x), _p(y), B, ncam, P, Cc, _stream()), "bevf_cam_mean_f32")
+    fn = "bevf_cam_mean_" + _sfx(x)
+    _check(getattr(lib(), fn)(_p(x, x.dtype), _p(y, x.dtype), B, ncam, P, Cc, _stream()), fn)
 
 
 def bilinear_nhwc(x, y, B: int, Hi: int, Wi: int, Cc: int, x_cs: int, Ho: int, Wo: int, y_cs: int):
     if x.numel() < (B * Hi * Wi - 1) * x_cs + Cc or y.numel() < (B * Ho * Wo - 1) * y_cs + Cc:
         raise BevfError("bilinear: buffer too small")
-    _check(lib().bevf_bilinear_nhwc_f32(_p(x), _p(y), B, Hi, Wi, Cc, x_cs, Ho, Wo, y_cs, _stream()),
-           "bevf_bilinear_nhwc_f32")
+    fn = "bevf_bilinear_nhwc_" + _sfx(x)
+    _check(getattr(lib(), fn)(_p(x, x.dtype), _p(y, x.dtype), B, Hi, Wi, Cc, x_cs, Ho, Wo, y_cs, _stream()), fn)
 
 
 def broadcast_nhwc(v, y, B: int, P: int, Cc: int, y_cs: int):
     if v.numel() < B * Cc or y.numel() < (B * P - 1) * y_cs + Cc:
         raise BevfError("broadcast: buffer too small")
-    _check(lib().bevf_broadcast_nhwc_f32(_p(v), _p(y), B, P, Cc, y_cs, _stream()), "bevf_broadcast_nhwc_f32")
+    fn = "bevf_broadcast_nhwc_" + _sfx(y)
+    _check(getattr(lib(), fn)(_p(v), _p(y, y.dtype), B, P, Cc, y_cs, _stream()), fn)
 
 
 def expand_border_classes(small, y, B: int, Sh: int, Sw: int, Cc: int, y_cs: int):
     if small.numel() < B * 25 * Cc or y.numel() < (B * Sh * Sw - 1) * y_cs + Cc:
         raise BevfError("expand: buffer too small")
-    _check(lib().bevf_expand_border_classes_f32(_p(small), _p(y), B, Sh, Sw, Cc, y_cs, _stream()),
-           "bevf_expand_border_classes_f32")
+    fn = "bevf_expand_border_classes_" + _sfx(small)
+    _check(getattr(lib(), fn)(_p(small, small.dtype), _p(y, small.dtype), B, Sh, Sw, Cc, y_cs, _stream()), fn)
 
 
 def head_tail(hid, w, bias, outs: Sequence[torch.Tensor], B: int, P: int, hc: int, cs: Sequence[int], n_sigmoid: int):
     if hid.numel() < B * P * 5 * hc or w.numel() != sum(cs) * hc or bias.numel() != sum(cs):
         raise BevfError("head_tail: buffer sizes wrong")
     d = HeadDesc()
-    d.hid, d.w, d.bias, d.B, d.P, d.hc, d.n_sigmoid = _p(hid), _pc(w), _pc(bias), B, P, hc, n_sigmoid
+    d.hid, d.w, d.bias, d.B, d.P, d.hc, d.n_sigmoid = _p(hid, hid.dtype), _pc(w), _pc(bias), B, P, hc, n_sigmoid
     for k in range(5):
         if outs[k].numel() != B * cs[k] * P:
             raise BevfError("head_tail: output size wrong")
         d.out[k], d.c[k] = _pc(outs[k]), cs[k]
-    _check(lib().bevf_head_tail_f32(C.byref(d), _stream()), "bevf_head_tail_f32")
+    fn = "bevf_head_tail_" + _sfx(hid)
+    _check(getattr(lib(), fn)(C.byref(d), _stream()), fn)
 
 
 def nchw_to_nhwc(x, y, N: int, Cc: int, P: int, y_cs: int):

@@ -13,19 +13,24 @@ static inline unsigned stream_grid(long long work_items) {
 }
 
 // y[b][p][c] = (x[b][0][p][c] + ... + x[b][n-1][p][c]) / n      ref src/fusion.py:233-234
-__global__ __launch_bounds__(256) void cam_mean(const f32x4* __restrict__ x, f32x4* __restrict__ y, int ncam,
-                                                 long long pc4, long long total) {
+template <typename T>
+__global__ __launch_bounds__(256) void cam_mean(const T* __restrict__ x, T* __restrict__ y, int ncam, long long pcv,
+                                                 long long total) {
+  constexpr int V = vec16<T>::N;
   const float div = (float)ncam;
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long b = i / pc4, r = i - b * pc4;
-    const f32x4* src = x + b * ncam * pc4 + r;
-    f32x4 s = src[0];
+    const long long b = i / pcv, r = i - b * pcv;
+    const T* src = x + (b * ncam * pcv + r) * V;
+    float s[V], v[V];
+    load16(src, s);
     for (int n = 1; n < ncam; ++n) {
-      const f32x4 v = src[(long long)n * pc4];
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      load16(src + (long long)n * pcv * V, v);
+#pragma unroll
+      for (int j = 0; j < V; ++j) s[j] += v[j];
     }
-    s.x /= div; s.y /= div; s.z /= div; s.w /= div;
-    y[i] = s;
+#pragma unroll
+    for (int j = 0; j < V; ++j) s[j] /= div;
+    store16(y + i * V, s);
   }
 }
 
@@ -41,13 +46,15 @@ __device__ __forceinline__ void lin_coord(int o, float scale, int in, int& i0, i
   l0 = 1.f - l1;
 }
 
-__global__ __launch_bounds__(256) void bilinear_nhwc(const float* __restrict__ x, float* __restrict__ y, int Hi,
-                                                      int Wi, int C, int x_cs, int Ho, int Wo, int y_cs,
-                                                      float sh, float sw, long long total) {
-  const int c4 = C >> 2;
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_nhwc(const T* __restrict__ x, T* __restrict__ y, int Hi, int Wi, int C,
+                                                      int x_cs, int Ho, int Wo, int y_cs, float sh, float sw,
+                                                      long long total) {
+  constexpr int V = vec16<T>::N;
+  const int cv = C / V;
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % c4) * 4;
-    long long pix = i / c4;
+    const int c = (int)(i % cv) * V;
+    long long pix = i / cv;
     const int ow = (int)(pix % Wo);
     const long long t = pix / Wo;
     const int oh = (int)(t % Ho), b = (int)(t / Ho);
@@ -55,27 +62,32 @@ __global__ __launch_bounds__(256) void bilinear_nhwc(const float* __restrict__ x
     float lh0, lh1, lw0, lw1;
     lin_coord(oh, sh, Hi, h0, h1, lh0, lh1);
     lin_coord(ow, sw, Wi, w0, w1, lw0, lw1);
-    const float* base = x + (size_t)b * Hi * Wi * x_cs + c;
-    const f32x4 p00 = *reinterpret_cast<const f32x4*>(base + ((size_t)h0 * Wi + w0) * x_cs);
-    const f32x4 p01 = *reinterpret_cast<const f32x4*>(base + ((size_t)h0 * Wi + w1) * x_cs);
-    const f32x4 p10 = *reinterpret_cast<const f32x4*>(base + ((size_t)h1 * Wi + w0) * x_cs);
-    const f32x4 p11 = *reinterpret_cast<const f32x4*>(base + ((size_t)h1 * Wi + w1) * x_cs);
-    f32x4 o;
+    const T* base = x + (size_t)b * Hi * Wi * x_cs + c;
+    float p00[V], p01[V], p10[V], p11[V], o[V];
+    load16(base + ((size_t)h0 * Wi + w0) * x_cs, p00);
+    load16(base + ((size_t)h0 * Wi + w1) * x_cs, p01);
+    load16(base + ((size_t)h1 * Wi + w0) * x_cs, p10);
+    load16(base + ((size_t)h1 * Wi + w1) * x_cs, p11);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < V; ++j)
       o[j] = lh0 * (lw0 * p00[j] + lw1 * p01[j]) + lh1 * (lw0 * p10[j] + lw1 * p11[j]);
-    *reinterpret_cast<f32x4*>(y + (size_t)pix * y_cs + c) = o;
+    store16(y + (size_t)pix * y_cs + c, o);
   }
 }
 
-__global__ __launch_bounds__(256) void broadcast_nhwc(const float* __restrict__ v, float* __restrict__ y, int P,
-                                                       int C, int y_cs, long long total) {
-  const int c4 = C >> 2;
+template <typename T>     // v is always fp32 (a B x C vector)
+__global__ __launch_bounds__(256) void broadcast_nhwc(const float* __restrict__ v, T* __restrict__ y, int P, int C,
+                                                       int y_cs, long long total) {
+  constexpr int V = vec16<T>::N;
+  const int cv = C / V;
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % c4) * 4;
-    const long long pix = i / c4;
+    const int c = (int)(i % cv) * V;
+    const long long pix = i / cv;
     const int b = (int)(pix / P);
-    *reinterpret_cast<f32x4*>(y + (size_t)pix * y_cs + c) = *reinterpret_cast<const f32x4*>(v + (size_t)b * C + c);
+    float f[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) f[j] = v[(size_t)b * C + c + j];
+    store16(y + (size_t)pix * y_cs + c, f);
   }
 }
 
@@ -86,25 +98,27 @@ __global__ __launch_bounds__(256) void broadcast_nhwc(const float* __restrict__ 
 // expands the 5x5 classes to the S_h x S_w map, written straight into the concat slice.
 __device__ __forceinline__ int border_class(int i, int S) { return i < 2 ? i : (i >= S - 2 ? 4 - (S - 1 - i) : 2); }
 
-__global__ __launch_bounds__(256) void expand_border_classes(const float* __restrict__ small, float* __restrict__ y,
-                                                              int Sh, int Sw, int C, int y_cs, long long total) {
-  const int c4 = C >> 2;
+template <typename T>
+__global__ __launch_bounds__(256) void expand_border_classes(const T* __restrict__ small, T* __restrict__ y, int Sh,
+                                                              int Sw, int C, int y_cs, long long total) {
+  constexpr int V = vec16<T>::N;
+  const int cv = C / V;
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % c4) * 4;
-    const long long pix = i / c4;
+    const int c = (int)(i % cv) * V;
+    const long long pix = i / cv;
     const int w = (int)(pix % Sw);
     const long long t = pix / Sw;
     const int hh = (int)(t % Sh), b = (int)(t / Sh);
     const f32x4 v = *reinterpret_cast<const f32x4*>(
         small + ((size_t)(b * 5 + border_class(hh, Sh)) * 5 + border_class(w, Sw)) * C + c);
-    *reinterpret_cast<f32x4*>(y + (size_t)pix * y_cs + c) = v;
+    *reinterpret_cast<f32x4*>(y + (size_t)pix * y_cs + c) = v;      // 16 raw bytes either way
   }
 }
 
 // CenterNet head tail (ref src/fusion.py:869-884): per pixel, five 1x1 convs on the five
 // hc-wide slices of the hidden map, sigmoid on the first n_sigmoid outputs, NCHW stores.
 struct HeadArgs {
-  const float* hid;
+  const void* hid;
   const float* w;
   const float* bias;
   float* out[5];
@@ -113,7 +127,9 @@ struct HeadArgs {
   int n_sigmoid;
 };
 
+template <typename T>
 __global__ __launch_bounds__(256) void head_tail(const HeadArgs a) {
+  constexpr int V = vec16<T>::N;
   extern __shared__ float wl[];   // [ctot][hc] then bias[ctot]
   const int ctot = a.c[0] + a.c[1] + a.c[2] + a.c[3] + a.c[4];
   for (int i = threadIdx.x; i < ctot * a.hc; i += 256) wl[i] = a.w[i];
@@ -123,16 +139,17 @@ __global__ __launch_bounds__(256) void head_tail(const HeadArgs a) {
   const long long total = (long long)a.B * a.P;
   for (long long pix = blockIdx.x * 256ll + threadIdx.x; pix < total; pix += (long long)gridDim.x * 256) {
     const int b = (int)(pix / a.P), p = (int)(pix - (long long)b * a.P);
-    const float* hp = a.hid + (size_t)pix * 5 * a.hc;
+    const T* hp = static_cast<const T*>(a.hid) + (size_t)pix * 5 * a.hc;
     int oc = 0;
     for (int k = 0; k < 5; ++k) {
       for (int c = 0; c < a.c[k]; ++c, ++oc) {
         float acc = 0.f;
-        for (int j = 0; j < a.hc; j += 4) {
-          const f32x4 hv = *reinterpret_cast<const f32x4*>(hp + k * a.hc + j);
+        for (int j = 0; j < a.hc; j += V) {
+          float hv[V];
+          load16(hp + k * a.hc + j, hv);
           const float* wr = wl + oc * a.hc + j;
-          acc = fmaf(hv.x, wr[0], acc); acc = fmaf(hv.y, wr[1], acc);
-          acc = fmaf(hv.z, wr[2], acc); acc = fmaf(hv.w, wr[3], acc);
+#pragma unroll
+          for (int q = 0; q < V; ++q) acc = fmaf(hv[q], wr[q], acc);
         }
         float v = acc + bl[oc];
         if (oc < a.n_sigmoid) v = 1.f / (1.f + expf(-v));
@@ -181,53 +198,90 @@ __global__ __launch_bounds__(256) void fill_f32(float* __restrict__ y, float v, 
 
 }  // namespace
 
-extern "C" int bevf_cam_mean_f32(const float* x, float* y, int B, int ncam, int P, int C, void* stream) {
+template <typename T>
+static int cam_mean_entry(const void* x, void* y, int B, int ncam, int P, int C, void* stream) {
+  constexpr int V = vec16<T>::N;
   BEVF_REQUIRE(x && y, "cam_mean: null pointer");
-  BEVF_REQUIRE(B > 0 && ncam > 0 && P > 0 && C > 0 && C % 4 == 0, "cam_mean: C=%d must be a positive multiple of 4", C);
+  BEVF_REQUIRE(B > 0 && ncam > 0 && P > 0 && C > 0 && C % V == 0, "cam_mean: C=%d must be a positive multiple of %d", C, V);
   BEVF_REQUIRE(bevf_aligned16(x) && bevf_aligned16(y), "cam_mean: unaligned");
-  const long long pc4 = (long long)P * C / 4, total = pc4 * B;
-  hipLaunchKernelGGL(cam_mean, dim3(stream_grid(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(y), ncam, pc4, total);
-  return bevf_check_launch("bevf_cam_mean_f32");
+  const long long pcv = (long long)P * C / V, total = pcv * B;
+  hipLaunchKernelGGL(cam_mean<T>, dim3(stream_grid(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const T*>(x), static_cast<T*>(y), ncam, pcv, total);
+  return bevf_check_launch("bevf_cam_mean");
+}
+extern "C" int bevf_cam_mean_f32(const float* x, float* y, int B, int ncam, int P, int C, void* stream) {
+  return cam_mean_entry<float>(x, y, B, ncam, P, C, stream);
+}
+extern "C" int bevf_cam_mean_bf16(const void* x, void* y, int B, int ncam, int P, int C, void* stream) {
+  return cam_mean_entry<__bf16>(x, y, B, ncam, P, C, stream);
 }
 
+template <typename T>
+static int bilinear_entry(const void* x, void* y, int B, int Hi, int Wi, int C, int x_cs, int Ho, int Wo, int y_cs,
+                          void* stream) {
+  constexpr int V = vec16<T>::N;
+  BEVF_REQUIRE(x && y, "bilinear: null pointer");
+  BEVF_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && C % V == 0, "bilinear: bad shape (C=%d)", C);
+  BEVF_REQUIRE(x_cs >= C && y_cs >= C && x_cs % V == 0 && y_cs % V == 0, "bilinear: channel strides must be >= C and 16-byte multiples");
+  BEVF_REQUIRE(bevf_aligned16(x) && bevf_aligned16(y), "bilinear: unaligned");
+  const long long total = (long long)B * Ho * Wo * (C / V);
+  hipLaunchKernelGGL(bilinear_nhwc<T>, dim3(stream_grid(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const T*>(x), static_cast<T*>(y), Hi, Wi, C, x_cs, Ho, Wo, y_cs, (float)Hi / (float)Ho,
+                     (float)Wi / (float)Wo, total);
+  return bevf_check_launch("bevf_bilinear_nhwc");
+}
 extern "C" int bevf_bilinear_nhwc_f32(const float* x, float* y, int B, int Hi, int Wi, int C, int x_cs, int Ho,
                                       int Wo, int y_cs, void* stream) {
-  BEVF_REQUIRE(x && y, "bilinear: null pointer");
-  BEVF_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0, "bilinear: bad shape (C=%d)", C);
-  BEVF_REQUIRE(x_cs >= C && y_cs >= C && x_cs % 4 == 0 && y_cs % 4 == 0, "bilinear: channel strides must be >= C and %%4");
-  BEVF_REQUIRE(bevf_aligned16(x) && bevf_aligned16(y), "bilinear: unaligned");
-  const long long total = (long long)B * Ho * Wo * (C / 4);
-  hipLaunchKernelGGL(bilinear_nhwc, dim3(stream_grid(total)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, Hi,
-                     Wi, C, x_cs, Ho, Wo, y_cs, (float)Hi / (float)Ho, (float)Wi / (float)Wo, total);
-  return bevf_check_launch("bevf_bilinear_nhwc_f32");
+  return bilinear_entry<float>(x, y, B, Hi, Wi, C, x_cs, Ho, Wo, y_cs, stream);
+}
+extern "C" int bevf_bilinear_nhwc_bf16(const void* x, void* y, int B, int Hi, int Wi, int C, int x_cs, int Ho, int Wo,
+                                       int y_cs, void* stream) {
+  return bilinear_entry<__bf16>(x, y, B, Hi, Wi, C, x_cs, Ho, Wo, y_cs, stream);
 }
 
-extern "C" int bevf_broadcast_nhwc_f32(const float* v, float* y, int B, int P, int C, int y_cs, void* stream) {
+template <typename T>
+static int broadcast_entry(const float* v, void* y, int B, int P, int C, int y_cs, void* stream) {
+  constexpr int V = vec16<T>::N;
   BEVF_REQUIRE(v && y, "broadcast: null pointer");
-  BEVF_REQUIRE(B > 0 && P > 0 && C > 0 && C % 4 == 0 && y_cs >= C && y_cs % 4 == 0, "broadcast: bad shape");
-  BEVF_REQUIRE(bevf_aligned16(v) && bevf_aligned16(y), "broadcast: unaligned");
-  const long long total = (long long)B * P * (C / 4);
-  hipLaunchKernelGGL(broadcast_nhwc, dim3(stream_grid(total)), dim3(256), 0, static_cast<hipStream_t>(stream), v, y, P,
-                     C, y_cs, total);
-  return bevf_check_launch("bevf_broadcast_nhwc_f32");
+  BEVF_REQUIRE(B > 0 && P > 0 && C > 0 && C % V == 0 && y_cs >= C && y_cs % V == 0, "broadcast: bad shape");
+  BEVF_REQUIRE(bevf_aligned16(y), "broadcast: unaligned");
+  const long long total = (long long)B * P * (C / V);
+  hipLaunchKernelGGL(broadcast_nhwc<T>, dim3(stream_grid(total)), dim3(256), 0, static_cast<hipStream_t>(stream), v,
+                     static_cast<T*>(y), P, C, y_cs, total);
+  return bevf_check_launch("bevf_broadcast_nhwc");
+}
+extern "C" int bevf_broadcast_nhwc_f32(const float* v, float* y, int B, int P, int C, int y_cs, void* stream) {
+  return broadcast_entry<float>(v, y, B, P, C, y_cs, stream);
+}
+extern "C" int bevf_broadcast_nhwc_bf16(const float* v, void* y, int B, int P, int C, int y_cs, void* stream) {
+  return broadcast_entry<__bf16>(v, y, B, P, C, y_cs, stream);
 }
 
+template <typename T>
+static int expand_entry(const void* small, void* y, int B, int Sh, int Sw, int C, int y_cs, void* stream) {
+  constexpr int V = vec16<T>::N;
+  BEVF_REQUIRE(small && y, "expand: null pointer");
+  BEVF_REQUIRE(B > 0 && Sh >= 5 && Sw >= 5 && C > 0 && C % V == 0 && y_cs >= C && y_cs % V == 0,
+               "expand: needs S >= 5 and 16-byte channel groups (Sh=%d Sw=%d C=%d)", Sh, Sw, C);
+  BEVF_REQUIRE(bevf_aligned16(small) && bevf_aligned16(y), "expand: unaligned");
+  const long long total = (long long)B * Sh * Sw * (C / V);
+  hipLaunchKernelGGL(expand_border_classes<T>, dim3(stream_grid(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const T*>(small), static_cast<T*>(y), Sh, Sw, C, y_cs, total);
+  return bevf_check_launch("bevf_expand_border_classes");
+}
 extern "C" int bevf_expand_border_classes_f32(const float* small, float* y, int B, int Sh, int Sw, int C, int y_cs,
                                              void* stream) {
-  BEVF_REQUIRE(small && y, "expand: null pointer");
-  BEVF_REQUIRE(B > 0 && Sh >= 5 && Sw >= 5 && C > 0 && C % 4 == 0 && y_cs >= C && y_cs % 4 == 0,
-               "expand: needs S >= 5 and C %% 4 == 0 (Sh=%d Sw=%d C=%d)", Sh, Sw, C);
-  BEVF_REQUIRE(bevf_aligned16(small) && bevf_aligned16(y), "expand: unaligned");
-  const long long total = (long long)B * Sh * Sw * (C / 4);
-  hipLaunchKernelGGL(expand_border_classes, dim3(stream_grid(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     small, y, Sh, Sw, C, y_cs, total);
-  return bevf_check_launch("bevf_expand_border_classes_f32");
+  return expand_entry<float>(small, y, B, Sh, Sw, C, y_cs, stream);
+}
+extern "C" int bevf_expand_border_classes_bf16(const void* small, void* y, int B, int Sh, int Sw, int C, int y_cs,
+                                              void* stream) {
+  return expand_entry<__bf16>(small, y, B, Sh, Sw, C, y_cs, stream);
 }
 
-extern "C" int bevf_head_tail_f32(const bevf_head_desc* d, void* stream) {
+template <typename T>
+static int head_tail_entry(const bevf_head_desc* d, void* stream) {
   BEVF_REQUIRE(d && d->hid && d->w && d->bias, "head_tail: null pointer");
-  BEVF_REQUIRE(d->B > 0 && d->P > 0 && d->hc > 0 && d->hc % 4 == 0, "head_tail: hc=%d must be a positive multiple of 4", d->hc);
+  BEVF_REQUIRE(d->B > 0 && d->P > 0 && d->hc > 0 && d->hc % vec16<T>::N == 0, "head_tail: hc=%d must be a positive multiple of %d", d->hc, vec16<T>::N);
   BEVF_REQUIRE(bevf_aligned16(d->hid), "head_tail: hid unaligned");
   HeadArgs a;
   a.hid = d->hid; a.w = d->w; a.bias = d->bias; a.B = d->B; a.P = d->P; a.hc = d->hc; a.n_sigmoid = d->n_sigmoid;
@@ -238,10 +292,12 @@ extern "C" int bevf_head_tail_f32(const bevf_head_desc* d, void* stream) {
   }
   const size_t lds = (size_t)ctot * (d->hc + 1) * sizeof(float);
   BEVF_REQUIRE(lds <= 64 * 1024, "head_tail: weights need %zu B of LDS", lds);
-  hipLaunchKernelGGL(head_tail, dim3(stream_grid((long long)d->B * d->P)), dim3(256), lds,
+  hipLaunchKernelGGL(head_tail<T>, dim3(stream_grid((long long)d->B * d->P)), dim3(256), lds,
                      static_cast<hipStream_t>(stream), a);
-  return bevf_check_launch("bevf_head_tail_f32");
+  return bevf_check_launch("bevf_head_tail");
 }
+extern "C" int bevf_head_tail_f32(const bevf_head_desc* d, void* stream) { return head_tail_entry<float>(d, stream); }
+extern "C" int bevf_head_tail_bf16(const bevf_head_desc* d, void* stream) { return head_tail_entry<__bf16>(d, stream); }
 
 extern "C" int bevf_nchw_to_nhwc_f32(const float* x, float* y, int N, int C, int P, int y_cs, void* stream) {
   BEVF_REQUIRE(x && y && N > 0 && C > 0 && P > 0 && y_cs >= C, "nchw_to_nhwc: bad arguments");

@@ -38,3 +38,34 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
+
+// ---- 16-byte channel vectors of either storage type (fp32: 4 channels, bf16: 8 channels) ----------------------
+template <typename T> struct vec16 { static constexpr int N = 16 / (int)sizeof(T); };
+template <typename T>
+__device__ __forceinline__ void load16(const T* p, float (&f)[vec16<T>::N]) {
+  if constexpr (sizeof(T) == 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = v[j];
+  } else {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (float)v[j];
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store16(T* p, const float (&f)[vec16<T>::N]) {
+  if constexpr (sizeof(T) == 4) {
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = f[j];
+    *reinterpret_cast<f32x4*>(p) = v;
+  } else {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    bf16x8_t v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (__bf16)f[j];
+    *reinterpret_cast<bf16x8_t*>(p) = v;
+  }
+}

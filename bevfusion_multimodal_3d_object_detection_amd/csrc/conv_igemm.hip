@@ -25,13 +25,17 @@
 
 namespace {
 
+// Element type T of activations / weights: float (v_mfma_f32_32x32x2_f32, exact fp32) or __bf16
+// (v_mfma_f32_32x32x16_bf16, fp32 accumulate).  Both share the byte geometry: a K step is 8 chunks of 16 B per
+// row (32 floats or 64 bf16), so staging, LDS layout, swizzle and fragment reads are identical; for bf16 the
+// 16-B fragment a lane reads (k = 8h..8h+7 of a 16-deep group) is exactly the MFMA's operand layout.
 struct ConvArgs {
-  const float* x;
-  const float* w;
+  const void* x;
+  const void* w;
   const float* scale;
   const float* shift;
-  const float* res;
-  float* y;
+  const void* res;
+  void* y;
   uint32_t* colmax;
   int N, H, W, Cin, x_cs;
   int Ho, Wo, Cout, y_cs, res_cs;
@@ -44,6 +48,7 @@ struct ConvArgs {
 constexpr int BK = 32;
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr unsigned kOob = 0x80000000u;   // >= num_records of every descriptor below: the load returns 0
 
 __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
@@ -58,9 +63,11 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigne
 // out-of-range offset, which the hardware answers with zeros), the filter tap moves the
 // descriptor's scalar base, the channel chunk is the scalar offset, LDS addresses are
 // precomputed and everything that varies per step is an instruction immediate.
-template <int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const int m_lo, const int m_hi,
                                           const int tm, const int tn) {
+  constexpr int ES = (int)sizeof(T), EPC = 16 / ES, BKE = 8 * EPC;   // element size, elements per chunk / K step
+  constexpr bool kF32 = std::is_same<T, float>::value;
   constexpr int WAVES_N = BN / WN;
   constexpr int MI = WM / 32, NI = WN / 32;
   constexpr int AP = BM / 32, BP = BN / 32;
@@ -84,7 +91,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const i
       const int n = m / HoWo, r = m - n * HoWo;
       const int oh = r / p.Wo, ow = r - oh * p.Wo;
       // byte offset of the pixel under filter tap (pad,pad); the tap itself moves the scalar base
-      a_voff[j] = (unsigned)((((n * p.H + oh * p.stride) * p.W + ow * p.stride) * p.x_cs + chunk * 4) * 4);
+      a_voff[j] = (unsigned)((((n * p.H + oh * p.stride) * p.W + ow * p.stride) * p.x_cs + chunk * EPC) * ES);
       a_ih0[j] = oh * p.stride - p.pad;
       a_iw0[j] = ow * p.stride - p.pad;
     } else {
@@ -97,10 +104,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const i
 #pragma unroll
   for (int j = 0; j < BP; ++j) {
     const int n = n0 + srow + 32 * j;
-    b_voff[j] = n < p.Cout ? (unsigned)(((size_t)n * p.K + chunk * 4) * 4) : kOob;
+    b_voff[j] = n < p.Cout ? (unsigned)(((size_t)n * p.K + chunk * EPC) * ES) : kOob;
   }
   const __amdgpu_buffer_rsrc_t rsrcB =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)kOob, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)kOob, 0x00020000);
 
   int kh = 0, kw = 0, c0 = 0;                       // scalar state of the NEXT tile to load
   auto set_tap = [&]() {                            // VALU work only when the filter tap changes
@@ -111,17 +118,17 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const i
     }
   };
   f32x4 ra[AP], rb[BP];
-  auto load_tile = [&](int kofs) {
-    const float* base = p.x + ((long)(kh - p.pad) * p.W + (kw - p.pad)) * p.x_cs;
+  auto load_tile = [&](int kstep) {
+    const char* base = static_cast<const char*>(p.x) + ((long)(kh - p.pad) * p.W + (kw - p.pad)) * p.x_cs * ES;
     const __amdgpu_buffer_rsrc_t rsrcA =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)kOob, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, (int)kOob, 0x00020000);
 #pragma unroll
-    for (int j = 0; j < AP; ++j) ra[j] = buf_load16(rsrcA, a_eff[j], (unsigned)c0 * 4u);
+    for (int j = 0; j < AP; ++j) ra[j] = buf_load16(rsrcA, a_eff[j], (unsigned)(c0 * ES));
 #pragma unroll
-    for (int j = 0; j < BP; ++j) rb[j] = buf_load16(rsrcB, b_voff[j], (unsigned)kofs * 4u);
+    for (int j = 0; j < BP; ++j) rb[j] = buf_load16(rsrcB, b_voff[j], (unsigned)kstep * 128u);
   };
   auto advance = [&]() {
-    c0 += BK;
+    c0 += BKE;
     if (c0 == p.Cin) {
       c0 = 0;
       if (++kw == p.KW) { kw = 0; ++kh; }
@@ -171,19 +178,28 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const i
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
         b[ni] = *reinterpret_cast<const f32x4*>(ldsb + b_rd[g] + buf * B_BYTES + ni * 4096);
+      if constexpr (kF32) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][s], b[ni][s], acc[mi][ni], 0, 0, 0);
+      } else {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][s], b[ni][s], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[mi]),
+                                                                  __builtin_bit_cast(bf16x8, b[ni]), acc[mi][ni], 0, 0, 0);
+      }
     }
   };
 
   // ---- K loop: loads for step t+1 are issued before the MFMAs of step t, written to the other
   //      LDS buffer after them; one barrier per step; unrolled by two so the buffer is static ----
-  const int KT = p.K / BK;
+  const int KT = p.K / BKE;
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
   set_tap();
@@ -193,14 +209,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const i
   int kt = 0;
   for (; kt + 2 <= KT; kt += 2) {
     advance();
-    load_tile((kt + 1) * BK);
+    load_tile(kt + 1);
     compute(B0{});
     store_tile(B1{});
     __syncthreads();
     const bool more = kt + 2 < KT;
     if (more) {
       advance();
-      load_tile((kt + 2) * BK);
+      load_tile(kt + 2);
     }
     compute(B1{});
     if (more) store_tile(B0{});
@@ -238,7 +254,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const i
         for (int r = 0; r < 16; ++r) {
           int m = mrow + (r & 3) + 8 * (r >> 2);
           m = m < m_hi ? m : m_hi - 1;
-          rv[r] = p.res[(size_t)m * p.res_cs + nc];
+          rv[r] = (float)static_cast<const T*>(p.res)[(size_t)m * p.res_cs + nc];
         }
       } else {
 #pragma unroll
@@ -254,7 +270,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const i
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = mrow + (r & 3) + 8 * (r >> 2);
-          if (m < m_hi && nok) p.y[(size_t)m * p.y_cs + n] = v[r];
+          if (m < m_hi && nok) static_cast<T*>(p.y)[(size_t)m * p.y_cs + n] = (T)v[r];
         }
       }
       if (p.colmax) {
@@ -279,27 +295,27 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const i
 }
 
 // single tile shape over all rows
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs p) {
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm(const ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int sid = xcd_remap(blockIdx.x, gridDim.x);
-  conv_tile<BM, BN, WM, WN>(p, lds, 0, p.M, sid / p.tilesN, sid % p.tilesN);
+  conv_tile<T, BM, BN, WM, WN>(p, lds, 0, p.M, sid / p.tilesN, sid % p.tilesN);
 }
 
 // big tiles over rows [0, m_split) + 64x64 tiles over rows [m_split, M) in one grid
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_f32_hybrid(const ConvArgs p) {
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_hybrid(const ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if ((int)blockIdx.x < p.nbig) {
     const int sid = xcd_remap(blockIdx.x, p.nbig);
-    conv_tile<BM, BN, WM, WN>(p, lds, 0, p.m_split, sid / p.tilesN_big, sid % p.tilesN_big);
+    conv_tile<T, BM, BN, WM, WN>(p, lds, 0, p.m_split, sid / p.tilesN_big, sid % p.tilesN_big);
   } else {
     const int sid = xcd_remap(blockIdx.x - p.nbig, gridDim.x - p.nbig);
-    conv_tile<64, 64, 32, 32>(p, lds, p.m_split, p.M, sid / p.tilesN, sid % p.tilesN);
+    conv_tile<T, 64, 64, 32, 32>(p, lds, p.m_split, p.M, sid / p.tilesN, sid % p.tilesN);
   }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN>
 int launch(const ConvArgs& a0, hipStream_t st) {
   ConvArgs a = a0;
   a.tilesM = (a.M + BM - 1) / BM;
@@ -308,15 +324,15 @@ int launch(const ConvArgs& a0, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
     if (lds_bytes > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<BM, BN, WM, WN>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm<T, BM, BN, WM, WN>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN>), dim3(a.tilesM * a.tilesN), dim3(256), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_igemm<T, BM, BN, WM, WN>), dim3(a.tilesM * a.tilesN), dim3(256), lds_bytes, st, a);
   return bevf_check_launch("bevf_conv2d_nhwc_f32");
 }
 
-template <int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN>
 int launch_hybrid(const ConvArgs& a0, int big_mtiles, hipStream_t st) {
   ConvArgs a = a0;
   a.tilesN_big = (a.Cout + BN - 1) / BN;
@@ -329,11 +345,11 @@ int launch_hybrid(const ConvArgs& a0, int big_mtiles, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
     if (lds_bytes > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32_hybrid<BM, BN, WM, WN>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_hybrid<T, BM, BN, WM, WN>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_igemm_f32_hybrid<BM, BN, WM, WN>), dim3(a.nbig + nsmall), dim3(256), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_igemm_hybrid<T, BM, BN, WM, WN>), dim3(a.nbig + nsmall), dim3(256), lds_bytes, st, a);
   return bevf_check_launch("bevf_conv2d_nhwc_f32");
 }
 
@@ -352,12 +368,14 @@ static int split_big_mtiles(long long M, int BM, int tilesN_big) {
 
 }  // namespace
 
-extern "C" int bevf_conv2d_nhwc_f32(const bevf_conv_desc* d, void* stream) {
+template <typename T>
+int conv_entry(const bevf_conv_desc* d, void* stream) {
+  constexpr int ES = (int)sizeof(T), BKE = 128 / ES;
   BEVF_REQUIRE(d && d->x && d->w, "conv: null x/w");
   BEVF_REQUIRE(d->y || d->colmax, "conv: neither y nor colmax given");
   BEVF_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->Cout > 0, "conv: empty shape");
-  BEVF_REQUIRE(d->Cin > 0 && d->Cin % 32 == 0, "conv: Cin=%d must be a positive multiple of 32", d->Cin);
-  BEVF_REQUIRE(d->x_cs >= d->Cin && d->x_cs % 4 == 0, "conv: x_cs=%d must be >= Cin and a multiple of 4", d->x_cs);
+  BEVF_REQUIRE(d->Cin > 0 && d->Cin % BKE == 0, "conv: Cin=%d must be a positive multiple of %d", d->Cin, BKE);
+  BEVF_REQUIRE(d->x_cs >= d->Cin && d->x_cs % (16 / ES) == 0, "conv: x_cs=%d must be >= Cin and a multiple of %d", d->x_cs, 16 / ES);
   BEVF_REQUIRE(bevf_aligned16(d->x) && bevf_aligned16(d->w), "conv: x/w must be 16-byte aligned");
   BEVF_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0, "conv: bad kernel geometry");
   BEVF_REQUIRE((d->H + 2 * d->pad - d->KH) / d->stride + 1 == d->Ho && (d->W + 2 * d->pad - d->KW) / d->stride + 1 == d->Wo,
@@ -365,8 +383,8 @@ extern "C" int bevf_conv2d_nhwc_f32(const bevf_conv_desc* d, void* stream) {
   BEVF_REQUIRE(!d->y || d->y_cs >= d->Cout, "conv: y_cs=%d < Cout=%d", d->y_cs, d->Cout);
   BEVF_REQUIRE(!d->res || d->res_cs >= d->Cout, "conv: res_cs < Cout");
   BEVF_REQUIRE(!d->colmax || (d->rows_per_group > 0 && d->relu), "conv: colmax needs rows_per_group > 0 and relu");
-  BEVF_REQUIRE((long long)d->N * d->H * d->W * d->x_cs * 4 < (1ll << 31) &&
-                   (long long)d->Cout * d->KH * d->KW * d->Cin * 4 < (1ll << 31),
+  BEVF_REQUIRE((long long)d->N * d->H * d->W * d->x_cs * ES < (1ll << 31) &&
+                   (long long)d->Cout * d->KH * d->KW * d->Cin * ES < (1ll << 31),
                "conv: input / weight buffers must stay below 2 GiB (32-bit buffer offsets)");
   const long long M = (long long)d->N * d->Ho * d->Wo;
   BEVF_REQUIRE(M < (1ll << 31) && (long long)d->N * d->H * d->W < (1ll << 31), "conv: pixel count overflows int32");
@@ -383,12 +401,12 @@ extern "C" int bevf_conv2d_nhwc_f32(const bevf_conv_desc* d, void* stream) {
 
   switch (d->tile) {
     case 0: break;
-    case 1: return launch<128, 128, 64, 64>(a, st);
-    case 2: return launch<256, 64, 64, 64>(a, st);
-    case 3: return launch<128, 64, 64, 32>(a, st);
-    case 4: return launch<64, 64, 32, 32>(a, st);
-    case 5: return launch_hybrid<128, 128, 64, 64>(a, (int)(M / 128) / 2, st);     // tests: forced mid split
-    case 6: return launch_hybrid<256, 64, 64, 64>(a, (int)(M / 256) / 2, st);
+    case 1: return launch<T, 128, 128, 64, 64>(a, st);
+    case 2: return launch<T, 256, 64, 64, 64>(a, st);
+    case 3: return launch<T, 128, 64, 64, 32>(a, st);
+    case 4: return launch<T, 64, 64, 32, 32>(a, st);
+    case 5: return launch_hybrid<T, 128, 128, 64, 64>(a, (int)(M / 128) / 2, st);     // tests: forced mid split
+    case 6: return launch_hybrid<T, 256, 64, 64, 64>(a, (int)(M / 256) / 2, st);
     default: bevf_set_error("conv: unknown tile variant %d", d->tile); return BEVF_ERR_ARG;
   }
   // auto: a small cost model over the tile shapes.  A CU runs `per_cu` workgroups of a shape at once (LDS-bound),
@@ -409,9 +427,12 @@ extern "C" int bevf_conv2d_nhwc_f32(const bevf_conv_desc* d, void* stream) {
     c128 = big > 0 ? rounds((double)big * tn, 2) * 128 * 128 * 2 + tail : 1e300;
   }
   if (c128 <= c128x64 && c128 <= c64) {
-    if (big == (int)((M + 127) / 128)) return launch<128, 128, 64, 64>(a, st);
-    return launch_hybrid<128, 128, 64, 64>(a, big, st);
+    if (big == (int)((M + 127) / 128)) return launch<T, 128, 128, 64, 64>(a, st);
+    return launch_hybrid<T, 128, 128, 64, 64>(a, big, st);
   }
-  if (c128x64 <= c64) return launch<128, 64, 64, 32>(a, st);
-  return launch<64, 64, 32, 32>(a, st);
+  if (c128x64 <= c64) return launch<T, 128, 64, 64, 32>(a, st);
+  return launch<T, 64, 64, 32, 32>(a, st);
 }
+
+extern "C" int bevf_conv2d_nhwc_f32(const bevf_conv_desc* d, void* stream) { return conv_entry<float>(d, stream); }
+extern "C" int bevf_conv2d_nhwc_bf16(const bevf_conv_desc* d, void* stream) { return conv_entry<__bf16>(d, stream); }

@@ -6,9 +6,10 @@ namespace {
 
 // ---- y[m][n] = act((sum_k x[m][k] w[n][k]) * scale[n] + shift[n]),  K <= 16 -------------------
 // PointNet conv1 + bn1 + relu (ref src/encoders.py:289).  Thread = (row, 4 channels).
+template <typename TO>
 __global__ __launch_bounds__(256) void pointwise_smallk(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ scale,
-                                                         const float* __restrict__ shift, float* __restrict__ y,
+                                                         const float* __restrict__ shift, TO* __restrict__ y,
                                                          int M, int K, int Cout, int relu) {
   extern __shared__ float wl[];  // [Cout][K]
   for (int i = threadIdx.x; i < Cout * K; i += 256) wl[i] = w[i];
@@ -20,15 +21,13 @@ __global__ __launch_bounds__(256) void pointwise_smallk(const float* __restrict_
     float xv[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) xv[k] = k < K ? x[(size_t)m * K + k] : 0.f;
-    f32x4 out;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float acc = 0.f;
       for (int k = 0; k < K; ++k) acc = fmaf(xv[k], wl[(n + j) * K + k], acc);
       float v = fmaf(acc, scale ? scale[n + j] : 1.f, shift ? shift[n + j] : 0.f);
-      out[j] = (relu && !(v > 0.f)) ? 0.f : v;
+      y[(size_t)m * Cout + n + j] = (TO)((relu && !(v > 0.f)) ? 0.f : v);
     }
-    *reinterpret_cast<f32x4*>(y + (size_t)m * Cout + n) = out;
   }
 }
 
@@ -101,27 +100,27 @@ __global__ __launch_bounds__(256) void radar_mlp_max(const RadarArgs a) {
 }
 
 // ---- dense layer, small batch: one wave per output row, weights streamed once -----------------
-template <int NB>
-__global__ __launch_bounds__(256) void linear_gemv(const float* __restrict__ x, const float* __restrict__ w,
-                                                    const float* __restrict__ bias, float* __restrict__ y, int K,
+template <int NB, typename TW, typename TY>      // x is always fp32 (a small B x K matrix); weights / outputs fp32 or bf16
+__global__ __launch_bounds__(256) void linear_gemv(const float* __restrict__ x, const TW* __restrict__ w,
+                                                    const float* __restrict__ bias, TY* __restrict__ y, int K,
                                                     int O, int relu, int perm_inner, int perm_outer) {
+  constexpr int V = vec16<TW>::N;
   const int lane = threadIdx.x & 63;
   const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
-  const int k4 = K >> 2;
+  const int kv = K / V;
   for (int o = wave_global; o < O; o += nwaves) {
-    const f32x4* wr = reinterpret_cast<const f32x4*>(w + (size_t)o * K);
+    const TW* wr = w + (size_t)o * K;
     float acc[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[b] = 0.f;
-    for (int i = lane; i < k4; i += 64) {
-      const f32x4 wv = wr[i];
+    for (int i = lane; i < kv; i += 64) {
+      float wv[V];
+      load16(wr + i * V, wv);
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
-        const f32x4 xv = reinterpret_cast<const f32x4*>(x + (size_t)b * K)[i];
-        acc[b] = fmaf(wv.x, xv.x, acc[b]);
-        acc[b] = fmaf(wv.y, xv.y, acc[b]);
-        acc[b] = fmaf(wv.z, xv.z, acc[b]);
-        acc[b] = fmaf(wv.w, xv.w, acc[b]);
+        const float* xb = x + (size_t)b * K + i * V;
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[b] = fmaf(wv[j], xb[j], acc[b]);
       }
     }
 #pragma unroll
@@ -135,7 +134,7 @@ __global__ __launch_bounds__(256) void linear_gemv(const float* __restrict__ x, 
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         const float v = acc[b] + bv;
-        y[(size_t)b * O + oo] = (relu && !(v > 0.f)) ? 0.f : v;
+        y[(size_t)b * O + oo] = (TY)((relu && !(v > 0.f)) ? 0.f : v);
       }
     }
   }
@@ -169,16 +168,24 @@ extern "C" int bevf_group_max_f32(const float* x, float* y, int G, int P, int C,
   return bevf_check_launch("bevf_group_max_f32");
 }
 
-extern "C" int bevf_pointwise_smallk_f32(const float* x, const float* w, const float* scale, const float* shift,
-                                         float* y, int M, int K, int Cout, int relu, void* stream) {
+template <typename TO>
+static int smallk_entry(const float* x, const float* w, const float* scale, const float* shift, void* y, int M, int K,
+                        int Cout, int relu, void* stream) {
   BEVF_REQUIRE(x && w && y, "pointwise: null pointer");
   BEVF_REQUIRE(M > 0 && K > 0 && K <= 16 && Cout > 0 && Cout % 4 == 0, "pointwise: need 0<K<=16, Cout%%4==0 (K=%d Cout=%d)", K, Cout);
-  BEVF_REQUIRE(bevf_aligned16(y), "pointwise: y unaligned");
   const long long total = (long long)M * (Cout / 4);
   const unsigned grid = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-  hipLaunchKernelGGL(pointwise_smallk, dim3(grid), dim3(256), (size_t)Cout * K * sizeof(float),
-                     static_cast<hipStream_t>(stream), x, w, scale, shift, y, M, K, Cout, relu);
-  return bevf_check_launch("bevf_pointwise_smallk_f32");
+  hipLaunchKernelGGL(pointwise_smallk<TO>, dim3(grid), dim3(256), (size_t)Cout * K * sizeof(float),
+                     static_cast<hipStream_t>(stream), x, w, scale, shift, static_cast<TO*>(y), M, K, Cout, relu);
+  return bevf_check_launch("bevf_pointwise_smallk");
+}
+extern "C" int bevf_pointwise_smallk_f32(const float* x, const float* w, const float* scale, const float* shift,
+                                         float* y, int M, int K, int Cout, int relu, void* stream) {
+  return smallk_entry<float>(x, w, scale, shift, y, M, K, Cout, relu, stream);
+}
+extern "C" int bevf_pointwise_smallk_bf16out(const float* x, const float* w, const float* scale, const float* shift,
+                                             void* y, int M, int K, int Cout, int relu, void* stream) {
+  return smallk_entry<__bf16>(x, w, scale, shift, y, M, K, Cout, relu, stream);
 }
 
 extern "C" int bevf_radar_mlp_max_f32(const bevf_radar_desc* d, void* stream) {
@@ -201,31 +208,43 @@ extern "C" int bevf_radar_mlp_max_f32(const bevf_radar_desc* d, void* stream) {
   return bevf_check_launch("bevf_radar_mlp_max_f32");
 }
 
-extern "C" int bevf_linear_f32(const float* x, const float* w, const float* bias, float* y, int B, int K, int O,
-                               int relu, int perm_inner, int perm_outer, void* stream) {
+template <typename TW, typename TY>
+static int linear_entry(const float* x, const void* w, const float* bias, void* y, int B, int K, int O, int relu,
+                        int perm_inner, int perm_outer, void* stream) {
   BEVF_REQUIRE(x && w && y, "linear: null pointer");
-  BEVF_REQUIRE(B > 0 && K > 0 && O > 0 && K % 4 == 0, "linear: K=%d must be a positive multiple of 4", K);
+  BEVF_REQUIRE(B > 0 && K > 0 && O > 0 && K % vec16<TW>::N == 0, "linear: K=%d must be a positive multiple of %d", K, vec16<TW>::N);
   BEVF_REQUIRE(bevf_aligned16(x) && bevf_aligned16(w), "linear: x/w unaligned");
   BEVF_REQUIRE(perm_inner <= 0 || (long long)perm_inner * perm_outer == O, "linear: perm_inner*perm_outer != O");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const unsigned grid = (unsigned)((O + 3) / 4 > 4096 ? 4096 : (O + 3) / 4);
+  const TW* wt = static_cast<const TW*>(w);
   for (int b0 = 0; b0 < B;) {
     const int rem = B - b0;
     const float* xb = x + (size_t)b0 * K;
-    float* yb = y + (size_t)b0 * O;
+    TY* yb = static_cast<TY*>(y) + (size_t)b0 * O;
     if (rem >= 8) {
-      hipLaunchKernelGGL(linear_gemv<8>, dim3(grid), dim3(256), 0, st, xb, w, bias, yb, K, O, relu, perm_inner, perm_outer);
+      hipLaunchKernelGGL((linear_gemv<8, TW, TY>), dim3(grid), dim3(256), 0, st, xb, wt, bias, yb, K, O, relu, perm_inner, perm_outer);
       b0 += 8;
     } else if (rem >= 4) {
-      hipLaunchKernelGGL(linear_gemv<4>, dim3(grid), dim3(256), 0, st, xb, w, bias, yb, K, O, relu, perm_inner, perm_outer);
+      hipLaunchKernelGGL((linear_gemv<4, TW, TY>), dim3(grid), dim3(256), 0, st, xb, wt, bias, yb, K, O, relu, perm_inner, perm_outer);
       b0 += 4;
     } else if (rem >= 2) {
-      hipLaunchKernelGGL(linear_gemv<2>, dim3(grid), dim3(256), 0, st, xb, w, bias, yb, K, O, relu, perm_inner, perm_outer);
+      hipLaunchKernelGGL((linear_gemv<2, TW, TY>), dim3(grid), dim3(256), 0, st, xb, wt, bias, yb, K, O, relu, perm_inner, perm_outer);
       b0 += 2;
     } else {
-      hipLaunchKernelGGL(linear_gemv<1>, dim3(grid), dim3(256), 0, st, xb, w, bias, yb, K, O, relu, perm_inner, perm_outer);
+      hipLaunchKernelGGL((linear_gemv<1, TW, TY>), dim3(grid), dim3(256), 0, st, xb, wt, bias, yb, K, O, relu, perm_inner, perm_outer);
       b0 += 1;
     }
   }
-  return bevf_check_launch("bevf_linear_f32");
+  return bevf_check_launch("bevf_linear");
+}
+extern "C" int bevf_linear_f32(const float* x, const float* w, const float* bias, float* y, int B, int K, int O,
+                               int relu, int perm_inner, int perm_outer, void* stream) {
+  return linear_entry<float, float>(x, w, bias, y, B, K, O, relu, perm_inner, perm_outer, stream);
+}
+// bf16 weights (half the bytes of the weight stream), fp32 activations in; output fp32 (y_bf16 == 0) or bf16
+extern "C" int bevf_linear_bf16w(const float* x, const void* w, const float* bias, void* y, int y_bf16, int B, int K,
+                                 int O, int relu, int perm_inner, int perm_outer, void* stream) {
+  return y_bf16 ? linear_entry<__bf16, __bf16>(x, w, bias, y, B, K, O, relu, perm_inner, perm_outer, stream)
+                : linear_entry<__bf16, float>(x, w, bias, y, B, K, O, relu, perm_inner, perm_outer, stream);
 }

@@ -39,9 +39,10 @@ __host__ __device__ constexpr StemStep stem_step(int p) {
   return {((2 * PR + 6) * PW + 6 + 1) * 4, 146 * 256, 3};                      // (2,6,6) | zero row 147
 }
 
-__global__ __launch_bounds__(256) void stem_conv7x7_f32(const float* __restrict__ x, const float* __restrict__ w,
-                                                         const float* __restrict__ scale,
-                                                         const float* __restrict__ shift, float* __restrict__ y,
+template <typename TO>
+__global__ __launch_bounds__(256) void stem_conv7x7(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, TO* __restrict__ y,
                                                          int H, int W, int Ho, int Wo, int tilesW, int tilesH,
                                                          int vec_ok, int relu) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -130,14 +131,14 @@ __global__ __launch_bounds__(256) void stem_conv7x7_f32(const float* __restrict_
       __builtin_amdgcn_sched_barrier(0);
     }
     // epilogue: column j = lane&31 -> channel, row i -> pixel wave*32 + i
-    float* yrow = y + ((size_t)(n * Ho + oh) * Wo + ow0) * 64;
+    TO* yrow = y + ((size_t)(n * Ho + oh) * Wo + ow0) * 64;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       if (ow0 + i < Wo) {
         const float v0 = fmaf(acc0[r], sc0, sh0), v1 = fmaf(acc1[r], sc1, sh1);
-        yrow[(size_t)i * 64 + l31] = relu ? fmaxf(v0, 0.f) : v0;
-        yrow[(size_t)i * 64 + l31 + 32] = relu ? fmaxf(v1, 0.f) : v1;
+        yrow[(size_t)i * 64 + l31] = (TO)(relu ? fmaxf(v0, 0.f) : v0);
+        yrow[(size_t)i * 64 + l31 + 32] = (TO)(relu ? fmaxf(v1, 0.f) : v1);
       }
     }
   }
@@ -145,18 +146,22 @@ __global__ __launch_bounds__(256) void stem_conv7x7_f32(const float* __restrict_
 
 constexpr size_t kStemLds = (size_t)(KPAD * 64 + 3 * PR * PW) * sizeof(float);
 
-// 3x3 stride-2 pad-1 max-pool on NHWC, 4 channels per thread.  ref src/encoders.py:157.
-__global__ __launch_bounds__(256) void maxpool3x3s2_nhwc(const float* __restrict__ x, float* __restrict__ y, int N,
-                                                          int H, int W, int C, int Ho, int Wo) {
-  const int c4 = C >> 2;
-  const long long total = (long long)N * Ho * Wo * c4;
+// 3x3 stride-2 pad-1 max-pool on NHWC, one 16-byte channel vector per thread.  ref src/encoders.py:157.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3x3s2_nhwc(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W,
+                                                          int C, int Ho, int Wo) {
+  constexpr int V = vec16<T>::N;
+  const int cv = C / V;
+  const long long total = (long long)N * Ho * Wo * cv;
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % c4);
-    long long pix = i / c4;
+    const int c = (int)(i % cv);
+    long long pix = i / cv;
     const int ow = (int)(pix % Wo);
     pix /= Wo;
     const int oh = (int)(pix % Ho), n = (int)(pix / Ho);
-    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    float m[V], v[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) m[j] = -INFINITY;
 #pragma unroll
     for (int dh = 0; dh < 3; ++dh) {
       const int ih = 2 * oh - 1 + dh;
@@ -165,18 +170,20 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc(const float* __restrict
       for (int dw = 0; dw < 3; ++dw) {
         const int iw = 2 * ow - 1 + dw;
         if ((unsigned)iw >= (unsigned)W) continue;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((size_t)(n * H + ih) * W + iw) * C + c * 4);
-        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        load16(x + ((size_t)(n * H + ih) * W + iw) * C + c * V, v);
+#pragma unroll
+        for (int j = 0; j < V; ++j) m[j] = fmaxf(m[j], v[j]);
       }
     }
-    *reinterpret_cast<f32x4*>(y + (size_t)i * 4) = m;
+    store16(y + (size_t)i * V, m);
   }
 }
 
 }  // namespace
 
-extern "C" int bevf_stem_conv7x7_f32(const float* x, const float* w, const float* scale, const float* shift,
-                                     float* y, int N, int H, int W, int relu, void* stream) {
+template <typename TO>
+static int stem_entry(const float* x, const float* w, const float* scale, const float* shift, void* y, int N, int H,
+                      int W, int relu, void* stream) {
   BEVF_REQUIRE(x && w && scale && shift && y, "stem: null pointer");
   BEVF_REQUIRE(bevf_aligned16(w), "stem: packed filter bank must be 16-byte aligned");
   BEVF_REQUIRE(N > 0 && H >= 1 && W >= 1, "stem: empty shape");
@@ -186,23 +193,41 @@ extern "C" int bevf_stem_conv7x7_f32(const float* x, const float* w, const float
   BEVF_REQUIRE(grid < (1ll << 31), "stem: grid too large");
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_conv7x7_f32),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_conv7x7<TO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStemLds);
     attr_done = true;
   }
-  hipLaunchKernelGGL(stem_conv7x7_f32, dim3((unsigned)grid), dim3(256), kStemLds, static_cast<hipStream_t>(stream), x,
-                     w, scale, shift, y, H, W, Ho, Wo, tilesW, tilesH, (W % 4 == 0 && bevf_aligned16(x)) ? 1 : 0, relu);
-  return bevf_check_launch("bevf_stem_conv7x7_f32");
+  hipLaunchKernelGGL(stem_conv7x7<TO>, dim3((unsigned)grid), dim3(256), kStemLds, static_cast<hipStream_t>(stream), x,
+                     w, scale, shift, static_cast<TO*>(y), H, W, Ho, Wo, tilesW, tilesH,
+                     (W % 4 == 0 && bevf_aligned16(x)) ? 1 : 0, relu);
+  return bevf_check_launch("bevf_stem_conv7x7");
+}
+extern "C" int bevf_stem_conv7x7_f32(const float* x, const float* w, const float* scale, const float* shift,
+                                     float* y, int N, int H, int W, int relu, void* stream) {
+  return stem_entry<float>(x, w, scale, shift, y, N, H, W, relu, stream);
+}
+// same computation (fp32 MFMA on the fp32 image), bf16 NHWC output for the bf16 path
+extern "C" int bevf_stem_conv7x7_bf16out(const float* x, const float* w, const float* scale, const float* shift,
+                                         void* y, int N, int H, int W, int relu, void* stream) {
+  return stem_entry<__bf16>(x, w, scale, shift, y, N, H, W, relu, stream);
 }
 
-extern "C" int bevf_maxpool3x3s2_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+template <typename T>
+static int maxpool_entry(const void* x, void* y, int N, int H, int W, int C, void* stream) {
+  constexpr int V = vec16<T>::N;
   BEVF_REQUIRE(x && y, "maxpool: null pointer");
-  BEVF_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "maxpool: C=%d must be a positive multiple of 4", C);
+  BEVF_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % V == 0, "maxpool: C=%d must be a positive multiple of %d", C, V);
   BEVF_REQUIRE(bevf_aligned16(x) && bevf_aligned16(y), "maxpool: unaligned");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  const long long total = (long long)N * Ho * Wo * (C / 4);
+  const long long total = (long long)N * Ho * Wo * (C / V);
   const unsigned grid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-  hipLaunchKernelGGL(maxpool3x3s2_nhwc, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, N, H, W, C,
-                     Ho, Wo);
-  return bevf_check_launch("bevf_maxpool3x3s2_nhwc_f32");
+  hipLaunchKernelGGL(maxpool3x3s2_nhwc<T>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const T*>(x), static_cast<T*>(y), N, H, W, C, Ho, Wo);
+  return bevf_check_launch("bevf_maxpool3x3s2_nhwc");
+}
+extern "C" int bevf_maxpool3x3s2_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+  return maxpool_entry<float>(x, y, N, H, W, C, stream);
+}
+extern "C" int bevf_maxpool3x3s2_nhwc_bf16(const void* x, void* y, int N, int H, int W, int C, void* stream) {
+  return maxpool_entry<__bf16>(x, y, N, H, W, C, stream);
 }

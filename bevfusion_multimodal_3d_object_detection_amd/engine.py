@@ -46,6 +46,7 @@ class PackedConv:
 
 
 def pack_conv(conv, bn=None, relu: bool = True) -> PackedConv:
+    """Weights keep the module's storage dtype (fp32 or bf16); the folded BN scale/shift are always fp32."""
     w = conv.weight.detach()
     if w.dim() == 3:                                   # Conv1d k=1 == pointwise
         w = w.unsqueeze(-1)
@@ -54,7 +55,7 @@ def pack_conv(conv, bn=None, relu: bool = True) -> PackedConv:
     stride = conv.stride[0] if isinstance(conv.stride, tuple) else conv.stride
     pad = conv.padding[0] if isinstance(conv.padding, tuple) else conv.padding
     scale, shift = _bn_fold(conv.bias, bn, cout, w.device)
-    return PackedConv(w.permute(0, 2, 3, 1).contiguous().view(-1).float(), scale, shift, cin, cout, kh, stride, pad, relu)
+    return PackedConv(w.permute(0, 2, 3, 1).contiguous().view(-1), scale, shift, cin, cout, kh, stride, pad, relu)
 
 
 def _check_eval(module: nn.Module) -> None:
@@ -91,7 +92,16 @@ class _Engine:
     def device(self):
         return next(self.module.parameters()).device
 
-    def buf(self, name: str, numel: int, dtype=torch.float32) -> torch.Tensor:
+    @property
+    def dtype(self):
+        """Storage dtype of activations = dtype of the module's parameters (fp32, or bf16 after model.bfloat16())."""
+        dt = next(self.module.parameters()).dtype
+        if dt not in (torch.float32, torch.bfloat16):
+            raise L.BevfError(f"unsupported parameter dtype {dt}: the HIP path stores fp32 or bf16")
+        return dt
+
+    def buf(self, name: str, numel: int, dtype=None) -> torch.Tensor:
+        dtype = self.dtype if dtype is None else dtype
         t = self._bufs.get(name)
         if t is None or t.numel() < numel or t.dtype != dtype or t.device != self.device:
             t = torch.empty(max(numel, 4), dtype=dtype, device=self.device)
@@ -170,7 +180,7 @@ def _conv_call(pc: PackedConv, x, y, N, H, W, x_cs=None, y_cs=None, res=None, co
 class CameraEncoderEngine(_Engine):
     def pack(self) -> None:
         m = self.module
-        w = m.conv1.weight.detach()                                     # (64,3,7,7)
+        w = m.conv1.weight.detach().float()                             # (64,3,7,7); the stem computes in fp32
         assert tuple(w.shape) == (64, 3, 7, 7), "stem kernel supports the ResNet 7x7x3->64 stem only"
         packed = torch.zeros(148, 64, device=w.device)
         packed[:147] = w.reshape(64, 147).t()
@@ -224,7 +234,7 @@ class PointNetEngine(_Engine):
         bns = [getattr(m, f"bn{i}") for i in range(1, 6)]
         w0 = convs[0].weight.detach()
         self.cin = w0.shape[1]
-        self.w0 = w0.reshape(w0.shape[0], self.cin).contiguous().float()
+        self.w0 = w0.reshape(w0.shape[0], self.cin).float().contiguous()
         self.s0, self.b0 = _bn_fold(convs[0].bias, bns[0], w0.shape[0], w0.device)
         self.c0 = w0.shape[0]
         self.layers = [pack_conv(c, b, True) for c, b in zip(convs[1:], bns[1:])]
@@ -235,7 +245,7 @@ class PointNetEngine(_Engine):
         B, N, Cc = pts.shape
         M = B * N
         a = self.buf("l0", M * self.c0)
-        L.pointwise_smallk(pts, self.w0, self.s0, self.b0, a, M, Cc, self.c0, True)
+        L.pointwise_smallk(pts.float(), self.w0, self.s0, self.b0, a, M, Cc, self.c0, True)
         for i, pc in enumerate(self.layers[:-1]):
             o = self.buf(f"l{i + 1}", M * pc.cout)
             _run_conv(pc, a, o, M, 1, 1)
@@ -255,7 +265,7 @@ class VFEEngine(_Engine):
         w = m.linear.weight.detach()
         self.cin, self.cout = w.shape[1], w.shape[0]
         self.scale, self.shift = _bn_fold(m.linear.bias, m.bn, self.cout, w.device)
-        self.w = w.contiguous().float()
+        self.w = w.float().contiguous()
         if self.cin > 16:
             if self.cin % 32:
                 raise L.BevfError(f"VFELayer: in_channels={self.cin} must be <= 16 or a multiple of 32")
@@ -286,13 +296,13 @@ class RadarEngine(_Engine):
         for i in range(1, 5):
             conv, bn = getattr(enc, f"conv{i}"), getattr(enc, f"bn{i}")
             w = conv.weight.detach()
-            self.ws.append(w.reshape(w.shape[0], w.shape[1]).t().contiguous().float())       # k-major
+            self.ws.append(w.reshape(w.shape[0], w.shape[1]).t().float().contiguous())       # k-major, fp32 compute
             s, b = _bn_fold(conv.bias, bn, w.shape[0], w.device)
             self.scales.append(s); self.shifts.append(b); self.widths.append(w.shape[0])
         if self.module.fusion_method == "concat":
             fc = self.module.fusion_fc
-            self.fc_w = fc.weight.detach().contiguous().float()
-            self.fc_b = fc.bias.detach().contiguous().float() if fc.bias is not None else None
+            self.fc_w = fc.weight.detach().contiguous()                 # storage dtype (fp32 / bf16 weight stream)
+            self.fc_b = fc.bias.detach().float().contiguous() if fc.bias is not None else None
 
     def run(self, radar_list: Sequence[torch.Tensor]) -> torch.Tensor:
         self.ensure_packed()
@@ -300,6 +310,7 @@ class RadarEngine(_Engine):
         B = radar_list[0].shape[0]
         feat = self.widths[3]
         per = torch.empty(B, R, feat, device=self.device)
+        radar_list = [r.float() for r in radar_list]
         same = all(r.shape == radar_list[0].shape for r in radar_list)
         if same:
             x = torch.stack([r.contiguous() for r in radar_list], dim=0).contiguous()         # [R][B][P][Cin]
@@ -338,13 +349,13 @@ class FusionEngine(_Engine):
             self.cam2 = pack_conv(m.camera_proj[3], m.camera_proj[4], True)
         if m.use_lidar:
             l0, l2 = m.lidar_init[0], m.lidar_init[2]
-            self.li0 = (l0.weight.detach().contiguous().float(), l0.bias.detach().contiguous().float())
-            self.li2 = (l2.weight.detach().contiguous().float(), l2.bias.detach().contiguous().float())
+            self.li0 = (l0.weight.detach().contiguous(), l0.bias.detach().float().contiguous())
+            self.li2 = (l2.weight.detach().contiguous(), l2.bias.detach().float().contiguous())
             self.lup1 = pack_conv(m.lidar_upsample[0], m.lidar_upsample[1], True)
             self.lup2 = pack_conv(m.lidar_upsample[4], m.lidar_upsample[5], True)
         if m.use_radar:
             r0 = m.radar_proj[0]
-            self.rp = (r0.weight.detach().contiguous().float(), r0.bias.detach().contiguous().float())
+            self.rp = (r0.weight.detach().contiguous(), r0.bias.detach().float().contiguous())
             self.rr1 = pack_conv(m.radar_refine[0], m.radar_refine[1], True)
             self.rr2 = pack_conv(m.radar_refine[3], m.radar_refine[4], True)
         self.f1 = pack_conv(m.bev_fusion[0], m.bev_fusion[1], True)
@@ -391,8 +402,8 @@ class FusionEngine(_Engine):
             slot += 1
         if "l" in present:
             s0 = m.lidar_start_size
-            hid = self.buf("lid_h", B * self.li0[0].shape[0])
-            L.linear(lidar.contiguous(), self.li0[0], self.li0[1], hid, B, self.li0[0].shape[1], self.li0[0].shape[0], True)
+            hid = self.buf("lid_h", B * self.li0[0].shape[0], torch.float32)       # small per-frame vectors stay fp32
+            L.linear(lidar.float().contiguous(), self.li0[0], self.li0[1], hid, B, self.li0[0].shape[1], self.li0[0].shape[0], True)
             O = self.li2[0].shape[0]
             ch = O // (s0 * s0)
             grid0 = self.buf("lid_g0", B * O)
@@ -412,8 +423,8 @@ class FusionEngine(_Engine):
                 L.bilinear_nhwc(g3, concat[slot * bc:], B, s1, s1, bc, bc, Sh, Sw, ccs)
             slot += 1
         if "r" in present:
-            rv = self.buf("rad_v", B * bc)
-            L.linear(radar.contiguous(), self.rp[0], self.rp[1], rv, B, self.rp[0].shape[1], bc, True)
+            rv = self.buf("rad_v", B * bc, torch.float32)
+            L.linear(radar.float().contiguous(), self.rp[0], self.rp[1], rv, B, self.rp[0].shape[1], bc, True)
             if Sh >= 5 and Sw >= 5 and self.collapse_radar:
                 # exact shortcut: two 3x3/pad-1 convs on a constant image have 5x5 distinct pixels (bevpool.hip)
                 r0 = self.buf("rad_0", B * 25 * bc)
@@ -450,18 +461,18 @@ class HeadEngine(_Engine):
         w3 = torch.cat([c.weight.detach() for c in convs3], dim=0)                 # (5*hc, Cin, 3, 3)
         b3 = torch.cat([c.bias.detach() for c in convs3], dim=0)
         self.hc = convs3[0].weight.shape[0]
-        self.conv = PackedConv(w3.permute(0, 2, 3, 1).contiguous().view(-1).float(), None, b3.contiguous().float(),
+        self.conv = PackedConv(w3.permute(0, 2, 3, 1).contiguous().view(-1), None, b3.float().contiguous(),
                                w3.shape[1], w3.shape[0], 3, 1, 1, True)
         self.cs = [c.weight.shape[0] for c in convs1]
-        self.w1 = torch.cat([c.weight.detach().reshape(c.weight.shape[0], self.hc) for c in convs1], 0).contiguous().float()
-        self.b1 = torch.cat([c.bias.detach() for c in convs1], 0).contiguous().float()
+        self.w1 = torch.cat([c.weight.detach().reshape(c.weight.shape[0], self.hc) for c in convs1], 0).float().contiguous()
+        self.b1 = torch.cat([c.bias.detach() for c in convs1], 0).float().contiguous()
 
     def run(self, bev_nhwc: torch.Tensor, B: int, H: int, W: int) -> Dict[str, torch.Tensor]:
         self.ensure_packed()
         P = H * W
         hid = self.buf("hid", B * P * self.conv.cout)
         _run_conv(self.conv, bev_nhwc, hid, B, H, W)
-        outs = [torch.empty(B, c, H, W, device=bev_nhwc.device) for c in self.cs]
+        outs = [torch.empty(B, c, H, W, device=bev_nhwc.device) for c in self.cs]        # fp32 also on the bf16 path
         L.head_tail(hid, self.w1, self.b1, outs, B, P, self.hc, self.cs, self.cs[0])
         return dict(zip(HEAD_BRANCHES, outs))
 
@@ -471,15 +482,17 @@ class HeadEngine(_Engine):
 def to_nhwc(x: torch.Tensor) -> torch.Tensor:
     """(N,C,H,W) -> flat NHWC buffer."""
     N, Cc, H, W = x.shape
+    dt = x.dtype
     y = torch.empty(N * H * W * Cc, device=x.device)
-    L.nchw_to_nhwc(x.contiguous(), y, N, Cc, H * W, Cc)
-    return y
+    L.nchw_to_nhwc(x.float().contiguous(), y, N, Cc, H * W, Cc)           # API-surface layout change runs in fp32
+    return y if dt == torch.float32 else y.to(dt)
 
 
 def to_nchw(buf: torch.Tensor, N: int, Cc: int, H: int, W: int) -> torch.Tensor:
+    dt = buf.dtype
     y = torch.empty(N, Cc, H, W, device=buf.device)
-    L.nhwc_to_nchw(buf, y, N, Cc, H * W, Cc)
-    return y
+    L.nhwc_to_nchw(buf.float(), y, N, Cc, H * W, Cc)
+    return y if dt == torch.float32 else y.to(dt)
 
 
 def require_cuda(*tensors) -> None:

@@ -107,10 +107,10 @@ class FlexibleBEVFusion(nn.Module):
             x = camera_features.float()
             if x.dim() == 5:
                 B, n, Cc, H, W = x.shape
-                cam_nhwc, cam_geom = E.to_nhwc(x.reshape(B * n, Cc, H, W)), (B, n, H, W)
+                cam_nhwc, cam_geom = E.to_nhwc(x.reshape(B * n, Cc, H, W)).to(self._eng().dtype), (B, n, H, W)
             else:
                 B, Cc, H, W = x.shape
-                cam_nhwc, cam_geom = E.to_nhwc(x), (B, 1, H, W)
+                cam_nhwc, cam_geom = E.to_nhwc(x).to(self._eng().dtype), (B, 1, H, W)
         out, B = self.forward_nhwc(cam_nhwc, cam_geom,
                                    lidar_features.float() if lidar_features is not None else None,
                                    radar_features.float() if radar_features is not None else None)
@@ -209,7 +209,7 @@ class CenterNetHead(nn.Module):
     def forward(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
         E.require_cuda(x)
         B, _, H, W = x.shape
-        return self.forward_nhwc(E.to_nhwc(x.float()), B, H, W)
+        return self.forward_nhwc(E.to_nhwc(x.float()).to(self._eng().dtype), B, H, W)
 
 
 class FlexibleMultiModal3DDetector(nn.Module):

@@ -220,6 +220,28 @@ size_t bevf_centernet_loss_work_floats(void);
 int bevf_centernet_loss_f32(const bevf_loss_desc* d, void* stream);
 
 /* ==========================================================================================
+ * bf16 storage, fp32 accumulate (BASELINE configs 3 and 5).  Same layouts and geometry as the fp32 entry
+ * points, element type bfloat16 wherever a pointer is typed void*: the convolution runs on
+ * v_mfma_f32_32x32x16_bf16 (a K step is 64 bf16 = the same 128-byte rows; needs Cin % 64 == 0), BN
+ * scale/shift, biases, the small per-frame vectors (PointNet / radar features) and the head outputs stay
+ * fp32.  bevf_conv2d_nhwc_bf16 takes the same descriptor with x / w / res / y pointing at bf16 data.
+ * ========================================================================================== */
+int bevf_conv2d_nhwc_bf16(const bevf_conv_desc* d, void* stream);
+int bevf_stem_conv7x7_bf16out(const float* x, const float* w, const float* scale, const float* shift, void* y, int N,
+                              int H, int W, int relu, void* stream);     /* fp32 image + fp32 MFMA, bf16 NHWC out */
+int bevf_maxpool3x3s2_nhwc_bf16(const void* x, void* y, int N, int H, int W, int C, void* stream);
+int bevf_pointwise_smallk_bf16out(const float* x, const float* w, const float* scale, const float* shift, void* y,
+                                  int M, int K, int Cout, int relu, void* stream);
+int bevf_linear_bf16w(const float* x, const void* w, const float* bias, void* y, int y_bf16, int B, int K, int O,
+                      int relu, int perm_inner, int perm_outer, void* stream);
+int bevf_cam_mean_bf16(const void* x, void* y, int B, int ncam, int P, int C, void* stream);
+int bevf_bilinear_nhwc_bf16(const void* x, void* y, int B, int Hi, int Wi, int C, int x_cs, int Ho, int Wo, int y_cs,
+                            void* stream);
+int bevf_broadcast_nhwc_bf16(const float* v, void* y, int B, int P, int C, int y_cs, void* stream);
+int bevf_expand_border_classes_bf16(const void* small, void* y, int B, int Sh, int Sw, int C, int y_cs, void* stream);
+int bevf_head_tail_bf16(const bevf_head_desc* d, void* stream);          /* hid bf16, outputs fp32 NCHW */
+
+/* ==========================================================================================
  * Training step (ref src/train_detect.py:401-434): the backward of every layer on
  * the path, train-mode BatchNorm, gradient clipping and AdamW.  Gradients accumulated with fp32 atomics
  * (conv weight gradient, bilinear / gather-L1 scatter) are not bitwise reproducible run to run.
