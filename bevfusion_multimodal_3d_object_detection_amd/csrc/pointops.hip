@@ -31,16 +31,19 @@ __global__ __launch_bounds__(256) void pointwise_smallk(const float* __restrict_
   }
 }
 
-// ---- radar: 4 x (pointwise linear + BN + ReLU) + max over points, per (radar, batch elem) -------
-// ref src/encoders.py:549-555.  Points are processed in chunks of 32 through two LDS buffers;
-// the last layer keeps a running per-channel maximum in registers (channel = thread).
+// ---- radar: 4 x (pointwise linear + BN + ReLU) + max over points --------------------------------------------
+// ref src/encoders.py:549-555.  One workgroup per (radar, batch element, chunk of 32 points); activations
+// ping-pong between two LDS buffers.  Thread = (output channel, point lane): the k loop is outermost so a
+// weight is read from global memory once per chunk (coalesced over channels) and reused from a register for the
+// thread's points, whose inputs are LDS broadcasts.  The last layer's per-chunk maximum goes out with an
+// integer atomicMax on the non-negative post-ReLU bit pattern (out zero-filled by the caller): deterministic.
 struct RadarArgs {
   const float* x;
   const float* w[4];      // k-major: [c_{i-1}][c_i]
   const float* scale[4];
   const float* shift[4];
   float* out;
-  int R, B, P, Cin;
+  int R, B, P, Cin, nchunks;
   int c[4];
 };
 constexpr int RCH = 32;   // points per chunk
@@ -48,54 +51,55 @@ constexpr int RCH = 32;   // points per chunk
 __global__ __launch_bounds__(256) void radar_mlp_max(const RadarArgs a) {
   extern __shared__ float sm[];
   const int cmax_a = a.c[0] > a.c[2] ? a.c[0] : a.c[2];
-  float* bufA = sm;                    // [RCH][max(Cin, c0, c2)]  input, layer-1 out, layer-3 out
-  float* bufB = sm + RCH * (cmax_a > a.Cin ? cmax_a : a.Cin);   // [RCH][c1]; layer-0 input lives in bufB first
-  const int r = blockIdx.x / a.B, b = blockIdx.x % a.B;
-  const float* xp = a.x + ((size_t)r * a.B + b) * a.P * a.Cin;
+  float* bufA = sm;                                               // [RCH][max(Cin, c0, c2)]
+  float* bufB = sm + RCH * (cmax_a > a.Cin ? cmax_a : a.Cin);     // [RCH][max(Cin, c1)]
+  const int chunk = blockIdx.x % a.nchunks, rb = blockIdx.x / a.nchunks;
+  const int r = rb / a.B, b = rb % a.B;
+  const int p0 = chunk * RCH, np = a.P - p0 < RCH ? a.P - p0 : RCH;
+  const float* xp = a.x + (((size_t)r * a.B + b) * a.P + p0) * a.Cin;
   const int tid = threadIdx.x;
-  float run_max[4] = {0.f, 0.f, 0.f, 0.f};      // channels tid, tid+256, ... of the last layer (post-ReLU >= 0)
-
-  for (int p0 = 0; p0 < a.P; p0 += RCH) {
-    const int np = a.P - p0 < RCH ? a.P - p0 : RCH;
-    // stage the chunk's raw points in bufB as [pt][Cin]
-    for (int i = tid; i < np * a.Cin; i += 256) bufB[i] = xp[(size_t)p0 * a.Cin + i];
-    __syncthreads();
-    const float* in = bufB;
-    float* outb = bufA;
-    int cin = a.Cin;
-    for (int l = 0; l < 3; ++l) {
-      const int co = a.c[l];
-      for (int i = tid; i < np * co; i += 256) {
-        const int pt = i / co, ch = i - pt * co;
-        float acc = 0.f;
-        for (int k = 0; k < cin; ++k) acc = fmaf(in[pt * cin + k], a.w[l][(size_t)k * co + ch], acc);
-        const float v = fmaf(acc, a.scale[l][ch], a.shift[l][ch]);
-        outb[pt * co + ch] = v > 0.f ? v : 0.f;
+  for (int i = tid; i < np * a.Cin; i += 256) bufB[i] = xp[i];
+  __syncthreads();
+  const float* in = bufB;
+  float* outb = bufA;
+  int cin = a.Cin;
+  for (int l = 0; l < 4; ++l) {
+    const int co = a.c[l];
+    for (int ch = tid % (co < 256 ? co : 256); ch < co; ch += 256) {     // co > 256: a thread takes several channels
+      const int lanes = co < 256 ? 256 / co : 1, pl = co < 256 ? tid / co : 0;
+      if (pl >= lanes) break;
+      float acc[RCH];
+#pragma unroll
+      for (int q = 0; q < RCH; ++q) acc[q] = 0.f;
+      for (int k = 0; k < cin; ++k) {
+        const float wv = a.w[l][(size_t)k * co + ch];
+#pragma unroll
+        for (int q = 0; q < RCH; ++q) {
+          const int pt = pl + q * lanes;
+          if (q * lanes < RCH && pt < np) acc[q] = fmaf(in[pt * cin + k], wv, acc[q]);
+        }
       }
-      __syncthreads();
-      in = outb;
-      outb = (outb == bufA) ? bufB : bufA;
-      cin = co;
-    }
-    // last layer: thread = channel, loop over the chunk's points, keep the maximum
-    const int co = a.c[3];
-    for (int j = 0; j < 4; ++j) {
-      const int ch = tid + 256 * j;
-      if (ch >= co) break;
-      const float sc = a.scale[3][ch], sh = a.shift[3][ch];
-      for (int pt = 0; pt < np; ++pt) {
-        float acc = 0.f;
-        for (int k = 0; k < cin; ++k) acc = fmaf(in[pt * cin + k], a.w[3][(size_t)k * co + ch], acc);
-        const float v = fmaf(acc, sc, sh);
-        run_max[j] = fmaxf(run_max[j], v);     // max(relu(v)) == max(0, v)
+      const float sc = a.scale[l][ch], sh = a.shift[l][ch];
+      if (l < 3) {
+#pragma unroll
+        for (int q = 0; q < RCH; ++q) {
+          const int pt = pl + q * lanes;
+          if (q * lanes < RCH && pt < np) outb[pt * co + ch] = fmaxf(fmaf(acc[q], sc, sh), 0.f);
+        }
+      } else {
+        float m = 0.f;                                              // max(relu(v)) == max(0, v)
+#pragma unroll
+        for (int q = 0; q < RCH; ++q) {
+          const int pt = pl + q * lanes;
+          if (q * lanes < RCH && pt < np) m = fmaxf(m, fmaf(acc[q], sc, sh));
+        }
+        atomicMax(reinterpret_cast<unsigned*>(a.out) + ((size_t)b * a.R + r) * co + ch, __float_as_uint(m));
       }
     }
     __syncthreads();
-  }
-  const int co = a.c[3];
-  for (int j = 0; j < 4; ++j) {
-    const int ch = tid + 256 * j;
-    if (ch < co) a.out[((size_t)b * a.R + r) * co + ch] = run_max[j];
+    in = outb;
+    outb = (outb == bufA) ? bufB : bufA;
+    cin = co;
   }
 }
 
@@ -204,7 +208,8 @@ extern "C" int bevf_radar_mlp_max_f32(const bevf_radar_desc* d, void* stream) {
   const int cmax_b = d->c[1] > d->Cin ? d->c[1] : d->Cin;
   const size_t lds = (size_t)RCH * (cmax_a + cmax_b) * sizeof(float);
   BEVF_REQUIRE(lds <= 64 * 1024, "radar: layer widths need %zu B of LDS", lds);
-  hipLaunchKernelGGL(radar_mlp_max, dim3(d->R * d->B), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+  a.nchunks = (d->P + RCH - 1) / RCH;
+  hipLaunchKernelGGL(radar_mlp_max, dim3(d->R * d->B * a.nchunks), dim3(256), lds, static_cast<hipStream_t>(stream), a);
   return bevf_check_launch("bevf_radar_mlp_max_f32");
 }
 

@@ -309,7 +309,7 @@ class RadarEngine(_Engine):
         R = len(radar_list)
         B = radar_list[0].shape[0]
         feat = self.widths[3]
-        per = torch.empty(B, R, feat, device=self.device)
+        per = torch.zeros(B, R, feat, device=self.device)            # zero-filled: chunk maxima merge with atomicMax
         radar_list = [r.float() for r in radar_list]
         same = all(r.shape == radar_list[0].shape for r in radar_list)
         if same:
@@ -317,7 +317,7 @@ class RadarEngine(_Engine):
             L.radar_mlp_max(x, self.ws, self.scales, self.shifts, per, R, B, x.shape[2], self.cin, self.widths)
         else:
             for r, pts in enumerate(radar_list):
-                one = torch.empty(B, 1, feat, device=self.device)
+                one = torch.zeros(B, 1, feat, device=self.device)
                 L.radar_mlp_max(pts.contiguous(), self.ws, self.scales, self.shifts, one, 1, B, pts.shape[1],
                                 self.cin, self.widths)
                 per[:, r] = one[:, 0]

@@ -86,7 +86,8 @@ int bevf_pointwise_smallk_f32(const float* x, const float* w, const float* scale
 int bevf_group_max_f32(const float* x, float* y, int G, int P, int C, void* stream);
 
 /* One radar sweep -> 256-d feature: 4 x (Conv1d k=1 + BN + ReLU) + max over points, all in
- * LDS, one workgroup per (radar, batch element).  ref src/encoders.py:549-555, loop :642-644.
+ * LDS, one workgroup per (radar, batch element, 32-point chunk); `out` must be ZERO-FILLED (the chunk maxima
+ * are merged with integer atomicMax).  ref src/encoders.py:549-555, loop :642-644.
  * x: [R][B][P][Cin]; w_i packed k-major [c_{i-1}][c_i]; out: [B][R][c4] (== torch.stack(dim=1)). */
 typedef struct {
   const float* x;
