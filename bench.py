@@ -33,6 +33,8 @@ CONFIGS = {
             modality="camera+lidar", cams=6, h=900, w=1600, points=35000, radars=0, bev=128),
     3: dict(name="camera+LiDAR+radar, 6x900x1600 + 35k points + 5x125 radar, BEV 128x128",
             modality="camera+lidar+radar", cams=6, h=900, w=1600, points=35000, radars=5, bev=128),
+    5: dict(name="bandwidth-stress: camera+LiDAR, 6x900x1600 + 120k-point 10-sweep LiDAR, BEV 256x256",
+            modality="camera+lidar", cams=6, h=900, w=1600, points=120000, radars=0, bev=256),
     # config 4: the reference's training step (src/train_detect.py: images resized to 448x800, BEV 50x50 targets)
     4: dict(name="train step camera+LiDAR, 6x448x800 + 35k points, BEV 50x50, 20 GT boxes/frame, AdamW + clip 10",
             modality="camera+lidar", cams=6, h=448, w=800, points=35000, radars=0, bev=50),
@@ -179,7 +181,7 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "BEV frames/sec (6-cam+LiDAR, 128x128 BEV)",
+            "metric": f"BEV frames/sec (6-cam+LiDAR, {cfg['bev']}x{cfg['bev']} BEV)",
             "value": replicas.aggregate_fps(args.batch * args.steps, world, elapsed), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
