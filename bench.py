@@ -120,9 +120,13 @@ def main():
 
     rank, local_rank, world = replicas.rank_world()
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = replicas.init("nccl", dev)              # RCCL; only for the barrier and the MAX of the elapsed time
+    # one process per GPU.  BEVF_DIST_BACKEND=gloo + fewer GPUs than ranks is a control-flow rehearsal only
+    # (ranks then share a device); the driver's runs use the default: RCCL, one GPU per rank.
+    backend = os.environ.get("BEVF_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    dist = replicas.init(backend, dev)             # RCCL; only for the barrier and the MAX of the elapsed time
     if args.mode == "train":
         args.config = 4
         if args.batch == 4:

@@ -44,6 +44,8 @@ def barrier(dist) -> None:
 def max_over_ranks(value: float, dist, device: torch.device) -> float:
     if dist is None:
         return value
+    if dist.get_backend() == "gloo":
+        device = torch.device("cpu")
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
