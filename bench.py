@@ -114,6 +114,7 @@ def main():
                     help="train = BASELINE config 4: fwd + targets + loss + bwd + grad all-reduce + clip + AdamW")
     ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32",
                     help="storage dtype of weights/activations (bf16 = BASELINE configs 3/5: bf16 storage, fp32 accumulate)")
+    ap.add_argument("--graph", action="store_true", help="replay the inference forward as one hipGraph (small batches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true", help="skip the per-launch HIP-event brackets")
     args = ap.parse_args()
@@ -161,6 +162,12 @@ def main():
             training.clip_grad_norm_(model.parameters(), 10.0)
             opt.step()
             return {k: v.detach() for k, v in losses.items()}
+    elif args.graph:
+        graphed = model.make_graphed(*inputs)
+        args.no_kernel_timer = True                     # per-launch event brackets cannot live inside a captured graph
+
+        def step():
+            return graphed(*inputs)
     else:
         def step():
             return model(*inputs)
@@ -192,7 +199,7 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": cfg["name"], "batch_per_gpu": args.batch,
                        "parallelism": f"replicas x{world}" if args.mode == "infer" else f"dp{world}",
-                       "weights": "random-init (synthetic, seeded)",
+                       "weights": "random-init (synthetic, seeded)", "launch": "hipGraph replay" if args.graph else "eager",
                        "mode": "inference forward -> 5 head tensors" if args.mode == "infer"
                        else "training step: fwd (train-mode BN) + targets + loss + bwd + grad all-reduce + clip + AdamW"},
         }
