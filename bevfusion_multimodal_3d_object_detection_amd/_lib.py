@@ -66,6 +66,12 @@ class HeadBwdDesc(C.Structure):
                 ("hc", C.c_int32), ("c", C.c_int32 * 5), ("n_sigmoid", C.c_int32)]
 
 
+class VoxelizeDesc(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("points", "voxel_features", "voxel_coords", "num_points", "num_voxels", "work")] + \
+               [(n, C.c_int32) for n in ("B", "N", "C", "max_points", "max_voxels")] + \
+               [("pc_range", C.c_float * 6), ("voxel_size", C.c_float * 3)]
+
+
 class LossDesc(C.Structure):
     _fields_ = [("pred_heatmap", C.c_void_p), ("tgt_heatmap", C.c_void_p), ("pred_reg", C.c_void_p * 4),
                 ("tgt_reg", C.c_void_p * 4), ("ind", C.c_void_p), ("reg_mask", C.c_void_p), ("work", C.c_void_p),
@@ -100,6 +106,8 @@ SIGNATURES = {
     "bevf_nms_keep_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 3 + [C.c_void_p]),
     "bevf_centernet_loss_work_floats": (C.c_size_t, []),
     "bevf_centernet_loss_f32": (C.c_int, [C.POINTER(LossDesc), C.c_void_p]),
+    "bevf_voxelize_work_bytes": (C.c_size_t, [C.c_int] * 2),
+    "bevf_voxelize_f32": (C.c_int, [C.POINTER(VoxelizeDesc), C.c_void_p]),
     # ---- bf16 storage path ----
     "bevf_conv2d_nhwc_bf16": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "bevf_stem_conv7x7_bf16out": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
@@ -422,3 +430,23 @@ def centernet_loss(pred: dict, tgt: dict, weights) -> torch.Tensor:
 def centernet_decode_raw(pred: dict, K: int):
     """Top-K bookkeeping only: voxel 1, origin 0, zero offsets -> boxes[...,0:2] are the integer (x, y) cells."""
     return centernet_decode(pred, K, -1.0, 1.0, 0.0, 0.0, False)
+
+
+def voxelize(points: torch.Tensor, pc_range, voxel_size, max_points: int, max_voxels: int):
+    if points.dim() != 3 or points.shape[2] < 3:
+        raise BevfError("voxelize: points must be (B, N, C>=3)")
+    B, N, Cc = points.shape
+    dev = points.device
+    feats = torch.zeros(B, max_voxels, max_points, Cc, device=dev)
+    coords = torch.zeros(B, max_voxels, 3, dtype=torch.int64, device=dev)
+    npts = torch.zeros(B, max_voxels, dtype=torch.int32, device=dev)
+    nvox = torch.zeros(B, dtype=torch.int32, device=dev)
+    work = torch.empty(lib().bevf_voxelize_work_bytes(B, N), dtype=torch.uint8, device=dev)
+    d = VoxelizeDesc(_pc(points), _p(feats), _p(coords, torch.int64), _p(npts, torch.int32), _p(nvox, torch.int32),
+                     _p(work, torch.uint8), B, N, Cc, max_points, max_voxels)
+    for i in range(6):
+        d.pc_range[i] = float(pc_range[i])
+    for i in range(3):
+        d.voxel_size[i] = float(voxel_size[i])
+    _check(lib().bevf_voxelize_f32(C.byref(d), _stream()), "bevf_voxelize_f32")
+    return feats, coords, npts, nvox

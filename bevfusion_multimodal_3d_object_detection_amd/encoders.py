@@ -276,6 +276,16 @@ class MultiRadarEncoder(nn.Module):
         return self._eng().run(rows)
 
 
+def voxelize(points: torch.Tensor, point_cloud_range=(-51.2, -51.2, -5.0, 51.2, 51.2, 3.0),
+             voxel_size=(2.048, 2.048, 8.0), max_points_per_voxel: int = 32, max_voxels: int = 12000):
+    """Hard voxelisation feeding `VFELayer` / `VoxelNetLiDAREncoder` (their docstrings, ref src/encoders.py:313-321,
+    describe exactly this input; the reference never builds it).  Defaults are the grid of configs/base.yaml:48-55
+    (50 x 50 pillars) and the reference's "32 points, 12000 voxels".  points (B,N,C) ->
+    voxel_features (B,Nv,P,C) zero padded, voxel_coords (B,Nv,3) int64 (z,y,x), num_points (B,Nv), num_voxels (B,)."""
+    E.require_cuda(points)
+    return L.voxelize(points.float().contiguous(), point_cloud_range, voxel_size, max_points_per_voxel, max_voxels)
+
+
 class VFELayer(nn.Module):
     """ref src/encoders.py:420-455 -- Linear -> BN1d over all B*Nv*P rows -> ReLU -> max over the P points
     of each voxel ("PointNet pillar reduction").  (B,Nv,P,C) -> (B,Nv,out_channels)."""

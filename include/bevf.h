@@ -220,6 +220,28 @@ typedef struct {
 size_t bevf_centernet_loss_work_floats(void);
 int bevf_centernet_loss_f32(const bevf_loss_desc* d, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Hard voxelisation: points -> the (voxel_features, voxel_coords) layout of
+ * VFELayer / VoxelNetLiDAREncoder (ref src/encoders.py:313-321, :385-387).  The reference contains no voxel
+ * assignment, so the semantics are the usual deterministic ones: cell = floor((p - range_min) / voxel_size)
+ * in fp32, out-of-grid points dropped, voxels numbered by first point, first max_points points per voxel in
+ * input order, zero padding.  Outputs must be zero-filled by the caller.  voxel_coords are (z, y, x) = the
+ * (D, H, W) index order of ref :399-410.  Grid dims = round((max - min) / voxel_size).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* points;       /* [B][N][C], x y z first */
+  float* voxel_features;     /* [B][max_voxels][max_points][C] */
+  int64_t* voxel_coords;     /* [B][max_voxels][3] */
+  int32_t* num_points;       /* [B][max_voxels] */
+  int32_t* num_voxels;       /* [B] */
+  void* work;                /* bevf_voxelize_work_bytes(B, N) bytes */
+  int32_t B, N, C, max_points, max_voxels;
+  float pc_range[6];
+  float voxel_size[3];
+} bevf_voxelize_desc;
+size_t bevf_voxelize_work_bytes(int B, int N);
+int bevf_voxelize_f32(const bevf_voxelize_desc* d, void* stream);
+
 /* ==========================================================================================
  * bf16 storage, fp32 accumulate (BASELINE configs 3 and 5).  Same layouts and geometry as the fp32 entry
  * points, element type bfloat16 wherever a pointer is typed void*: the convolution runs on
