@@ -132,7 +132,8 @@ __global__ __launch_bounds__(256) void vox_fill(const VoxArgs a, const unsigned 
 
 size_t sort_temp_bytes(long long n) {
   size_t bytes = 0;
-  hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (int)n, 0, 64);
+  (void)hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, (const unsigned long long*)nullptr,
+                                          (unsigned long long*)nullptr, (int)n, 0, 64);
   return bytes;
 }
 
