@@ -150,7 +150,8 @@ def main():
         boxes, labels = synth.gt_boxes(args.batch, 20, seed=replicas.frame_seed(0x5EED, args.config, rank))
         gt = {"gt_boxes": boxes.to(dev), "gt_labels": labels.to(dev)}
         crit = ct.CenterNetLoss()
-        opt = training.FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.01)     # ref train_detect.py:725-741
+        # ref train_detect.py:725-741 (AdamW lr 1e-4 wd 0.01) and :431 (clip_grad_norm_ 10), clip folded into the update
+        opt = training.FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.01, max_grad_norm=10.0)
 
         def step():
             pred = model(*inputs)
@@ -159,7 +160,6 @@ def main():
             opt.zero_grad()
             losses["total_loss"].backward()
             replicas.allreduce_gradients(model.parameters(), dist)                    # RCCL, DP only
-            training.clip_grad_norm_(model.parameters(), 10.0)
             opt.step()
             return {k: v.detach() for k, v in losses.items()}
     elif args.graph:

@@ -43,6 +43,7 @@ struct ConvArgs {
   int relu, rows_per_group;
   int M, K, tilesM, tilesN;
   int m_split, nbig, tilesN_big;   // hybrid launch: blocks [0,nbig) = big tiles over rows [0,m_split)
+  unsigned div_hw_mul, div_hw_sh, div_w_mul, div_w_sh;   // m / (Ho*Wo) and r / Wo as multiply-high + shift
 };
 
 constexpr int BK = 32;
@@ -56,6 +57,26 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigne
   return __builtin_bit_cast(f32x4, v);
 }
 
+// Division of a dividend < 2^31 by a launch constant: q = umulhi(n, mul) >> sh with mul = ceil(2^(31+s)/d),
+// s = ceil(log2 d), sh = s-1 (exact for every n < 2^31 because the rounding error e < d <= 2^s); mul = 0 means d = 1.
+__device__ __forceinline__ int fastdiv(int n, unsigned mul, unsigned sh) {
+  return mul ? (int)(__umulhi((unsigned)n, mul) >> sh) : n;
+}
+static void fastdiv_make(int d, unsigned* mul, unsigned* sh) {
+  if (d <= 1) { *mul = 0; *sh = 0; return; }
+  int s = 0;
+  while ((1ll << s) < d) ++s;
+  *mul = (unsigned)(((1ull << (31 + s)) + (unsigned long long)d - 1) / (unsigned long long)d);
+  *sh = (unsigned)(s - 1);
+}
+
+// Why prologue and epilogue are written for a minimal VALU count: v_mfma_f32_32x32x2_f32 occupies the SIMD's
+// vector pipe for 64 cycles, and a VALU instruction of ANY wave on that SIMD waits for the MFMA in flight --
+// measured with s_memrealtime stamps: ~300 VALU instructions of tile set-up took 8 us (64 cycles each) next to two
+// other workgroups' MFMA streams, and so did the epilogue; together a third of a layer1 workgroup's lifetime, during
+// which it contributes no MFMA work.  Hence: multiply-high instead of integer division, scalar (wave-uniform) row
+// addresses in the epilogue, compile-time residual / ReLU variants, no per-element bounds logic on full tiles.
+//
 // K-loop design notes (what the ISA must look like): v_mfma_f32_32x32x2_f32 runs at the fp32
 // VALU rate, so every VALU instruction in the loop costs MFMA issue time.  The loop therefore
 // has no per-step address arithmetic: global operands come through buffer loads whose per-lane
@@ -75,7 +96,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const i
   constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 4;   // one buffer each
   char* const ldsb = reinterpret_cast<char*>(lds);              // [A0][A1][B0][B1]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // scalar: wave-uniform addresses stay in SGPRs
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int m0 = m_lo + tm * BM, n0 = tn * BN;
 
@@ -88,8 +110,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const i
   for (int j = 0; j < AP; ++j) {
     const int m = m0 + srow + 32 * j;
     if (m < m_hi) {
-      const int n = m / HoWo, r = m - n * HoWo;
-      const int oh = r / p.Wo, ow = r - oh * p.Wo;
+      const int n = fastdiv(m, p.div_hw_mul, p.div_hw_sh), r = m - n * HoWo;
+      const int oh = fastdiv(r, p.div_w_mul, p.div_w_sh), ow = r - oh * p.Wo;
       // byte offset of the pixel under filter tap (pad,pad); the tap itself moves the scalar base
       a_voff[j] = (unsigned)((((n * p.H + oh * p.stride) * p.W + ow * p.stride) * p.x_cs + chunk * EPC) * ES);
       a_ih0[j] = oh * p.stride - p.pad;
@@ -159,16 +181,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const i
       *reinterpret_cast<f32x4*>(ldsb + wr_off + 2 * A_BYTES + buf * B_BYTES + j * 4096) = rb[j];
   };
 
-  f32x16 acc[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-  auto compute = [&](auto bufc) {
+  f32x16 acc[MI][NI];                                 // no zero fill: the very first MFMA of a tile takes C = 0
+  auto compute = [&](auto bufc, auto firstc) {
     constexpr int buf = decltype(bufc)::value;
+    constexpr bool first = decltype(firstc)::value;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       f32x4 a[MI], b[NI];
@@ -185,14 +202,16 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const i
           for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][s], b[ni][s], acc[mi][ni], 0, 0, 0);
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][s], b[ni][s],
+                                                                 first && g == 0 && s == 0 ? zero : acc[mi][ni], 0, 0, 0);
       } else {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[mi]),
-                                                                  __builtin_bit_cast(bf16x8, b[ni]), acc[mi][ni], 0, 0, 0);
+                                                                  __builtin_bit_cast(bf16x8, b[ni]),
+                                                                  first && g == 0 ? zero : acc[mi][ni], 0, 0, 0);
       }
     }
   };
@@ -206,11 +225,33 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const i
   load_tile(0);
   store_tile(B0{});
   __syncthreads();
+  using First = std::true_type;
+  using Later = std::false_type;
   int kt = 0;
+  if (KT >= 2) {                                    // peeled first pair: the first MFMA starts the accumulators
+    advance();
+    load_tile(1);
+    compute(B0{}, First{});
+    store_tile(B1{});
+    __syncthreads();
+    const bool more = 2 < KT;
+    if (more) {
+      advance();
+      load_tile(2);
+    }
+    compute(B1{}, Later{});
+    if (more) store_tile(B0{});
+    __syncthreads();
+    kt = 2;
+  } else {
+    compute(B0{}, First{});                         // KT == 1
+    __syncthreads();
+    kt = 1;
+  }
   for (; kt + 2 <= KT; kt += 2) {
     advance();
     load_tile(kt + 1);
-    compute(B0{});
+    compute(B0{}, Later{});
     store_tile(B1{});
     __syncthreads();
     const bool more = kt + 2 < KT;
@@ -218,12 +259,12 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const i
       advance();
       load_tile(kt + 2);
     }
-    compute(B1{});
+    compute(B1{}, Later{});
     if (more) store_tile(B0{});
     __syncthreads();
   }
   if (kt < KT) {                                    // odd number of K steps: the last one sits in buffer 0
-    compute(B0{});
+    compute(B0{}, Later{});
     __syncthreads();
   }
 
@@ -231,6 +272,55 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const i
   // Branch-free per element: residual loads of a 32x32 tile are issued as one batch (rows past
   // the end are clamped for the load and masked at the store).
   const int m_base = m0 + wm * WM, n_base = n0 + wn * WN;
+  if (!p.colmax && m0 + BM <= m_hi && n0 + BN <= p.Cout) {
+    // full tile: buffer stores whose row offset is the instruction's SCALAR offset (SALU arithmetic) and whose
+    // lane offset is computed once; residual / ReLU chosen once -- 2-3 VALU instructions per output element
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        static_cast<T*>(p.y) + (size_t)m_base * p.y_cs + n_base, 0, (int)kOob, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(static_cast<const T*>(p.res)) + (size_t)m_base * p.res_cs + n_base, 0, (int)kOob, 0x00020000);
+    const unsigned y_lane = (unsigned)((4 * h * p.y_cs + l31) * ES);
+    const unsigned r_lane = (unsigned)((4 * h * p.res_cs + l31) * ES);
+    auto run = [&](auto has_res, auto do_relu) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const float sc = p.scale ? p.scale[n_base + ni * 32 + l31] : 1.f;
+        const float sh = p.shift ? p.shift[n_base + ni * 32 + l31] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          float rv[16];
+          if constexpr (decltype(has_res)::value) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const unsigned so = (unsigned)(((mi * 32 + (r & 3) + 8 * (r >> 2)) * p.res_cs + ni * 32) * ES);
+              if constexpr (kF32) {
+                rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, r_lane, so, 0));
+              } else {
+                const unsigned short u = __builtin_amdgcn_raw_buffer_load_b16(rr, r_lane, so, 0);
+                rv[r] = __builtin_bit_cast(float, (unsigned)u << 16);
+              }
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float t = fmaf(acc[mi][ni][r], sc, sh);
+            if constexpr (decltype(has_res)::value) t += rv[r];
+            if constexpr (decltype(do_relu)::value) t = fmaxf(t, 0.f);
+            const unsigned so = (unsigned)(((mi * 32 + (r & 3) + 8 * (r >> 2)) * p.y_cs + ni * 32) * ES);
+            if constexpr (kF32)
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), ry, y_lane, so, 0);
+            else
+              __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)t), ry, y_lane, so, 0);
+          }
+        }
+      }
+    };
+    using TT = std::true_type;
+    using FF = std::false_type;
+    if (p.res) { if (p.relu) run(TT{}, TT{}); else run(TT{}, FF{}); }
+    else       { if (p.relu) run(FF{}, TT{}); else run(FF{}, FF{}); }
+    return;
+  }
   bool cm_fast = false;
   int cm_group = 0;
   if (p.colmax) {
@@ -397,6 +487,8 @@ int conv_entry(const bevf_conv_desc* d, void* stream) {
   a.relu = d->relu; a.rows_per_group = d->rows_per_group;
   a.M = (int)M; a.K = d->KH * d->KW * d->Cin; a.tilesM = a.tilesN = 0;
   a.m_split = 0; a.nbig = 0; a.tilesN_big = 0;
+  fastdiv_make(d->Ho * d->Wo, &a.div_hw_mul, &a.div_hw_sh);
+  fastdiv_make(d->Wo, &a.div_w_mul, &a.div_w_sh);
   hipStream_t st = static_cast<hipStream_t>(stream);
 
   switch (d->tile) {

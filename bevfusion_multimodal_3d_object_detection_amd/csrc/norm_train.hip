@@ -8,7 +8,7 @@
 
 namespace {
 
-constexpr int kStatGrid = 256;
+constexpr int kStatGrid = 1024;
 
 // thread (cq, rl): channel quad cq = tid % C4, row lane rl = tid / C4; C4 = C/4 <= 256 and a power of two * ...
 struct RowMap {
@@ -28,7 +28,18 @@ __global__ __launch_bounds__(256) void stats_partials(const float* __restrict__ 
     if (rl >= lanes) break;
     const f32x4 sh = *reinterpret_cast<const f32x4*>(x + cq * 4);
     float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
-    for (long long m = (long long)blockIdx.x * lanes + rl; m < M; m += (long long)gridDim.x * lanes) {
+    const long long step = (long long)gridDim.x * lanes;
+    long long m = (long long)blockIdx.x * lanes + rl;
+    for (; m + 3 * step < M; m += 4 * step) {           // four independent 16-byte loads in flight per thread
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(x + (size_t)(m + u * step) * cs + cq * 4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[u][j] - sh[j]; a1[j] += d; a2[j] = fmaf(d, d, a2[j]); }
+    }
+    for (; m < M; m += step) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)m * cs + cq * 4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) { const float d = v[j] - sh[j]; a1[j] += d; a2[j] = fmaf(d, d, a2[j]); }
@@ -65,15 +76,15 @@ __global__ __launch_bounds__(256) void stats_partials(const float* __restrict__ 
   }
 }
 
-// merge of the G per-workgroup partials of one channel: 8 lanes take g = lane, lane+8, ... (fixed order), then a
-// fixed-order sum of the 8 lane totals; 32 channels per workgroup
+// merge of the G per-workgroup partials of one channel: one wave per channel, lane l takes g = l, l+64, ... (fixed
+// order), then a fixed xor tree over the 64 lane totals; 4 channels per workgroup
 __device__ __forceinline__ void merge_partials(const float* __restrict__ part, int C, int G, int c, int gl, double& s1,
                                                double& s2) {
   s1 = 0; s2 = 0;
   if (c < C)
-    for (int g = gl; g < G; g += 8) { s1 += part[((size_t)g * C + c) * 2]; s2 += part[((size_t)g * C + c) * 2 + 1]; }
+    for (int g = gl; g < G; g += 64) { s1 += part[((size_t)g * C + c) * 2]; s2 += part[((size_t)g * C + c) * 2 + 1]; }
 #pragma unroll
-  for (int sft = 1; sft < 8; sft <<= 1) {                 // lanes of one channel are 8 consecutive threads
+  for (int sft = 1; sft < 64; sft <<= 1) {
     s1 += __shfl_xor(s1, sft);
     s2 += __shfl_xor(s2, sft);
   }
@@ -83,7 +94,7 @@ __device__ __forceinline__ void merge_partials(const float* __restrict__ part, i
 __global__ __launch_bounds__(256) void stats_finalize(const float* __restrict__ x, const float* __restrict__ part,
                                                        float* __restrict__ mean, float* __restrict__ var,
                                                        float* __restrict__ invstd, int M, int C, int G, float eps) {
-  const int c = blockIdx.x * 32 + (threadIdx.x >> 3), gl = threadIdx.x & 7;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), gl = threadIdx.x & 63;
   double s1, s2;
   merge_partials(part, C, G, c, gl, s1, s2);
   if (c >= C || gl != 0) return;
@@ -94,27 +105,56 @@ __global__ __launch_bounds__(256) void stats_finalize(const float* __restrict__ 
   invstd[c] = (float)(1.0 / sqrt((v > 0 ? v : 0) + (double)eps));
 }
 
-// y = act((x - mean) * invstd * gamma + beta (+ res))
+// y = act((x - mean) * invstd * gamma + beta (+ res)).  Thread (cq, rl) keeps channel quad cq for its whole life, so
+// the per-channel scale/shift live in registers and the row loop is pure 16-byte streaming with 4 rows in flight.
 __global__ __launch_bounds__(256) void bn_apply(const float* __restrict__ x, const float* __restrict__ mean,
                                                  const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                  const float* __restrict__ beta, const float* __restrict__ res,
                                                  float* __restrict__ y, long long M, int C, int cs, int relu) {
   const int c4 = C >> 2;
-  const long long total = M * c4;
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % c4) * 4;
-    const long long m = i / c4;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)m * cs + c);
-    f32x4 o;
+  const int lanes = c4 >= 256 ? 1 : 256 / c4;
+  const int rl = c4 >= 256 ? 0 : threadIdx.x / c4;
+  if (rl >= lanes) return;
+  const long long step = (long long)gridDim.x * lanes;
+  for (int cq = threadIdx.x % (c4 < 256 ? c4 : 256); cq < c4; cq += 256) {
+    const int c = cq * 4;
+    float a[4], b[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float a = (gamma ? gamma[c + j] : 1.f) * invstd[c + j];
-      const float b = (beta ? beta[c + j] : 0.f) - mean[c + j] * a;
-      float t = fmaf(v[j], a, b);
-      if (res) t += res[(size_t)m * C + c + j];
-      o[j] = relu ? fmaxf(t, 0.f) : t;
+      a[j] = (gamma ? gamma[c + j] : 1.f) * invstd[c + j];
+      b[j] = (beta ? beta[c + j] : 0.f) - mean[c + j] * a[j];
     }
-    *reinterpret_cast<f32x4*>(y + (size_t)m * C + c) = o;
+    long long m = (long long)blockIdx.x * lanes + rl;
+    for (; m + 3 * step < M; m += 4 * step) {
+      f32x4 v[4], r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v[u] = *reinterpret_cast<const f32x4*>(x + (size_t)(m + u * step) * cs + c);
+        if (res) r[u] = *reinterpret_cast<const f32x4*>(res + (size_t)(m + u * step) * C + c);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float t = fmaf(v[u][j], a[j], b[j]);
+          if (res) t += r[u][j];
+          o[j] = relu ? fmaxf(t, 0.f) : t;
+        }
+        *reinterpret_cast<f32x4*>(y + (size_t)(m + u * step) * C + c) = o;
+      }
+    }
+    for (; m < M; m += step) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)m * cs + c);
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t = fmaf(v[j], a[j], b[j]);
+        if (res) t += res[(size_t)m * C + c + j];
+        o[j] = relu ? fmaxf(t, 0.f) : t;
+      }
+      *reinterpret_cast<f32x4*>(y + (size_t)m * C + c) = o;
+    }
   }
 }
 
@@ -134,7 +174,32 @@ __global__ __launch_bounds__(256) void bn_bwd_partials(float* __restrict__ dy, c
 #pragma unroll
     for (int j = 0; j < 4; ++j) { mu[j] = mean ? mean[cq * 4 + j] : 0.f; is[j] = invstd ? invstd[cq * 4 + j] : 1.f; }
     float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
-    for (long long m = (long long)blockIdx.x * lanes + rl; m < M; m += (long long)gridDim.x * lanes) {
+    const long long step = (long long)gridDim.x * lanes;
+    long long m = (long long)blockIdx.x * lanes + rl;
+    for (; m + 3 * step < M; m += 4 * step) {           // 4 rows x up to 3 streams of 16-byte loads in flight
+      f32x4 g[4], yy[4], xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t r = (size_t)(m + u * step);
+        g[u] = *reinterpret_cast<const f32x4*>(dy + r * C + cq * 4);
+        if (relu) yy[u] = *reinterpret_cast<const f32x4*>(y + r * C + cq * 4);
+        if (x) xv[u] = *reinterpret_cast<const f32x4*>(x + r * cs + cq * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (relu) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) g[u][j] = yy[u][j] > 0.f ? g[u][j] : 0.f;
+          *reinterpret_cast<f32x4*>(dy + (size_t)(m + u * step) * C + cq * 4) = g[u];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          a1[j] += g[u][j];
+          if (x) a2[j] = fmaf(g[u][j], (xv[u][j] - mu[j]) * is[j], a2[j]);
+        }
+      }
+    }
+    for (; m < M; m += step) {
       f32x4 g = *reinterpret_cast<const f32x4*>(dy + (size_t)m * C + cq * 4);
       if (relu) {
         const f32x4 yy = *reinterpret_cast<const f32x4*>(y + (size_t)m * C + cq * 4);
@@ -185,7 +250,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partials(float* __restrict__ dy, c
 
 __global__ __launch_bounds__(256) void sums_finalize(const float* __restrict__ part, float* __restrict__ s_dy,
                                                       float* __restrict__ s_dyx, int C, int G) {
-  const int c = blockIdx.x * 32 + (threadIdx.x >> 3), gl = threadIdx.x & 7;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), gl = threadIdx.x & 63;
   double s1, s2;
   merge_partials(part, C, G, c, gl, s1, s2);
   if (c >= C || gl != 0) return;
@@ -193,33 +258,60 @@ __global__ __launch_bounds__(256) void sums_finalize(const float* __restrict__ p
   if (s_dyx) s_dyx[c] = (float)s2;
 }
 
-// backward stage 2: dx = gamma*invstd * (dy - sum_dy/M - xhat * sum_dyx/M)
+// backward stage 2: dx = gamma*invstd * (dy - sum_dy/M - xhat * sum_dyx/M) = k1*dy + k2*x + k3 per channel
 __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ s_dy,
                                                      const float* __restrict__ s_dyx, float* __restrict__ dx,
                                                      long long M, int C, int cs) {
   const int c4 = C >> 2;
-  const long long total = M * c4;
+  const int lanes = c4 >= 256 ? 1 : 256 / c4;
+  const int rl = c4 >= 256 ? 0 : threadIdx.x / c4;
+  if (rl >= lanes) return;
+  const long long step = (long long)gridDim.x * lanes;
   const float invM = 1.f / (float)M;
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % c4) * 4;
-    const long long m = i / c4;
-    const f32x4 g = *reinterpret_cast<const f32x4*>(dy + (size_t)m * C + c);
-    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)m * cs + c);
-    f32x4 o;
+  for (int cq = threadIdx.x % (c4 < 256 ? c4 : 256); cq < c4; cq += 256) {
+    const int c = cq * 4;
+    float gi[4], is[4], mu[4], sd[4], sx[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float is = invstd[c + j], xh = (xv[j] - mean[c + j]) * is;
-      o[j] = (gamma ? gamma[c + j] : 1.f) * is * (g[j] - s_dy[c + j] * invM - xh * s_dyx[c + j] * invM);
+      is[j] = invstd[c + j];
+      mu[j] = mean[c + j];
+      gi[j] = (gamma ? gamma[c + j] : 1.f) * is[j];
+      sd[j] = s_dy[c + j] * invM;
+      sx[j] = s_dyx[c + j] * invM;
     }
-    *reinterpret_cast<f32x4*>(dx + (size_t)m * cs + c) = o;
+    long long m = (long long)blockIdx.x * lanes + rl;
+    for (; m + 3 * step < M; m += 4 * step) {
+      f32x4 g[4], xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        g[u] = *reinterpret_cast<const f32x4*>(dy + (size_t)(m + u * step) * C + c);
+        xv[u] = *reinterpret_cast<const f32x4*>(x + (size_t)(m + u * step) * cs + c);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = gi[j] * (g[u][j] - sd[j] - (xv[u][j] - mu[j]) * is[j] * sx[j]);
+        *reinterpret_cast<f32x4*>(dx + (size_t)(m + u * step) * cs + c) = o;
+      }
+    }
+    for (; m < M; m += step) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(dy + (size_t)m * C + c);
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)m * cs + c);
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = gi[j] * (g[j] - sd[j] - (xv[j] - mu[j]) * is[j] * sx[j]);
+      *reinterpret_cast<f32x4*>(dx + (size_t)m * cs + c) = o;
+    }
   }
 }
 
-static inline unsigned ew_grid(long long items) {
-  long long g = (items + 255) / 256;
-  return (unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+static inline unsigned row_grid(long long M, int C) {      // workgroups for the row-streaming kernels
+  const int lanes = C / 4 >= 256 ? 1 : 256 / (C / 4);
+  long long g = (M + (long long)lanes * 4 - 1) / ((long long)lanes * 4);
+  return (unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
 }
 
 }  // namespace
@@ -236,7 +328,7 @@ extern "C" int bevf_bn_stats_f32(const float* x, float* work, float* mean, float
   int G = (M + lanes - 1) / lanes;
   if (G > kStatGrid) G = kStatGrid;
   hipLaunchKernelGGL(stats_partials, dim3(G), dim3(256), 256 * 8 * sizeof(float), st, x, work, M, C, cs);
-  hipLaunchKernelGGL(stats_finalize, dim3((C + 31) / 32), dim3(256), 0, st, x, work, mean, var, invstd, M, C, G, eps);
+  hipLaunchKernelGGL(stats_finalize, dim3((C + 3) / 4), dim3(256), 0, st, x, work, mean, var, invstd, M, C, G, eps);
   return bevf_check_launch("bevf_bn_stats_f32");
 }
 
@@ -246,7 +338,7 @@ extern "C" int bevf_bn_apply_f32(const float* x, const float* mean, const float*
   BEVF_REQUIRE(x && mean && invstd && y, "bn_apply: null pointer");
   BEVF_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && cs >= C && cs % 4 == 0, "bn_apply: bad shape");
   BEVF_REQUIRE(bevf_aligned16(x) && bevf_aligned16(y) && (!res || bevf_aligned16(res)), "bn_apply: unaligned");
-  hipLaunchKernelGGL(bn_apply, dim3(ew_grid((long long)M * (C / 4))), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+  hipLaunchKernelGGL(bn_apply, dim3(row_grid(M, C)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
                      mean, invstd, gamma, beta, res, y, (long long)M, C, cs, relu);
   return bevf_check_launch("bevf_bn_apply_f32");
 }
@@ -264,9 +356,9 @@ extern "C" int bevf_bn_backward_f32(float* dy, const float* y, const float* x, c
   if (G > kStatGrid) G = kStatGrid;
   hipLaunchKernelGGL(bn_bwd_partials, dim3(G), dim3(256), 256 * 8 * sizeof(float), st, dy, y, x, mean, invstd, work, M, C,
                      cs, relu);
-  hipLaunchKernelGGL(sums_finalize, dim3((C + 31) / 32), dim3(256), 0, st, work, dbeta, dgamma, C, G);
+  hipLaunchKernelGGL(sums_finalize, dim3((C + 3) / 4), dim3(256), 0, st, work, dbeta, dgamma, C, G);
   if (dx)
-    hipLaunchKernelGGL(bn_bwd_apply, dim3(ew_grid((long long)M * (C / 4))), dim3(256), 0, st, dy, x, mean, invstd, gamma,
+    hipLaunchKernelGGL(bn_bwd_apply, dim3(row_grid(M, C)), dim3(256), 0, st, dy, x, mean, invstd, gamma,
                        dbeta, dgamma, dx, (long long)M, C, cs);
   return bevf_check_launch("bevf_bn_backward_f32");
 }

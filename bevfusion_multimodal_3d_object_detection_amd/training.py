@@ -648,12 +648,18 @@ class _DetectorTrainFn(torch.autograd.Function):
         with torch.no_grad():
             outs = tape.forward(imgs, pts, radars)
         ctx.tape, ctx.params = tape, params
-        return tuple(outs)
+        # The tape keeps its own tensors; autograd gets fresh aliases.  Returning the tape's objects would close a
+        # reference cycle through C++ (output -> grad_fn -> ctx.tape -> output) that the garbage collector cannot
+        # see: every step's activations (~11 GiB at config 4) would stay allocated for ever.
+        return tuple(o.detach() for o in outs)
 
     @staticmethod
     def backward(ctx, *douts):
+        if ctx.tape is None:
+            raise RuntimeError("Trying to backward through the detector a second time: its saved activations were freed")
         with torch.no_grad():
             sink = ctx.tape.backward(list(douts))
+        ctx.tape = None                                   # activations are dead now: hand them back to the allocator
         grads = []
         for p in ctx.params:
             g = sink.get(p)
@@ -736,25 +742,64 @@ def clip_grad_norm_(parameters, max_norm: float) -> torch.Tensor:
 
 
 class FusedAdamW(torch.optim.Optimizer):
-    """torch.optim.AdamW semantics (ref src/train_detect.py:725-741: lr 1e-4, weight_decay 0.01) on bevf_adamw_step_f32."""
+    """torch.optim.AdamW semantics (ref src/train_detect.py:725-741: lr 1e-4, weight_decay 0.01) on bevf_adamw_step_f32.
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    The parameters that receive gradients are moved into ONE flat fp32 arena on the first step (each Parameter becomes
+    a view of it, so state_dict / load_state_dict keep working); a step is then one gradient gather, optionally the
+    global-norm clip of ref src/train_detect.py:431 (`max_grad_norm`, folded into the update as a device-side
+    factor), and one AdamW launch over the whole arena instead of one per tensor."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=None):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.max_grad_norm = max_grad_norm
+        self.last_grad_norm: Optional[torch.Tensor] = None
+        self._arenas = None
+
+    def _build(self):
+        self._arenas = []
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                self._arenas.append(None)
+                continue
+            dev = ps[0].device
+            if dev.type != "cuda" or any(p.dtype != torch.float32 or p.device != dev for p in ps):
+                raise RuntimeError("FusedAdamW: parameters must be fp32 tensors on one cuda device")
+            n = sum(p.numel() for p in ps)
+            flat = torch.empty(n, device=dev)
+            off = 0
+            for p in ps:
+                k = p.numel()
+                flat[off:off + k].copy_(p.detach().reshape(-1))
+                p.data = flat[off:off + k].view(p.shape)
+                off += k
+            self._arenas.append(dict(params=ps, flat=flat, m=torch.zeros(n, device=dev), v=torch.zeros(n, device=dev),
+                                     work=torch.empty(512, dtype=torch.float64, device=dev),
+                                     clip=torch.empty(2, device=dev), step=0))
 
     @torch.no_grad()
     def step(self, closure=None):
-        for group in self.param_groups:
+        if self._arenas is None:
+            self._build()
+        for group, ar in zip(self.param_groups, self._arenas):
+            with_grad = [p for p in group["params"] if p.grad is not None]
+            if ar is None:
+                if with_grad:
+                    raise RuntimeError("FusedAdamW: the set of parameters with gradients changed; build a new optimiser")
+                continue
+            if len(with_grad) != len(ar["params"]) or any(a is not b for a, b in zip(with_grad, ar["params"])):
+                raise RuntimeError("FusedAdamW: the set of parameters with gradients changed; build a new optimiser")
+            g = torch.cat([p.grad.reshape(-1) for p in with_grad])
+            clip = None
+            if self.max_grad_norm is not None:
+                _ck(_lib().bevf_grad_norm_f32(g.data_ptr(), g.numel(), ar["work"].data_ptr(), float(self.max_grad_norm),
+                                              ar["clip"].data_ptr(), _st()), "bevf_grad_norm_f32")
+                clip = ar["clip"].data_ptr()
+                self.last_grad_norm = ar["clip"][0]
+            ar["step"] += 1
             b1, b2 = group["betas"]
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
-                st = self.state[p]
-                if not st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                st["step"] += 1
-                g = p.grad.contiguous()
-                _ck(_lib().bevf_adamw_step_f32(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
-                                               st["exp_avg_sq"].data_ptr(), None, p.numel(), group["lr"], b1, b2,
-                                               group["eps"], group["weight_decay"], st["step"], _st()), "bevf_adamw_step_f32")
+            _ck(_lib().bevf_adamw_step_f32(ar["flat"].data_ptr(), g.data_ptr(), ar["m"].data_ptr(), ar["v"].data_ptr(), clip,
+                                           g.numel(), group["lr"], b1, b2, group["eps"], group["weight_decay"], ar["step"],
+                                           _st()), "bevf_adamw_step_f32")
+            for p in with_grad:                      # the kernel wrote through raw pointers: tell torch (and the
+                torch.autograd.graph.increment_version(p)   # engines' repack signature) that the values changed

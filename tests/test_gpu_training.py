@@ -157,6 +157,52 @@ def test_train_step_golden(gpu, opt_name):
     assert int(model.camera_encoder.bn1.num_batches_tracked) == 4
 
 
+def test_train_steps_do_not_leak_device_memory(gpu):
+    """Activations of a step are released when its backward has run (no autograd reference cycle)."""
+    import gc
+    c, model, imgs, pts, boxes, labels = _train_case()
+    opt = training.FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.01, max_grad_norm=10.0)
+    tgt = ct.prepare_centernet_targets({"gt_boxes": boxes, "gt_labels": labels}, gpu)
+    used = []
+    gc.disable()
+    try:
+        for _ in range(4):
+            losses = ct.CenterNetLoss()(model(imgs, pts, None), tgt)
+            opt.zero_grad()
+            losses["total_loss"].backward()
+            opt.step()
+            del losses
+            torch.cuda.synchronize()
+            used.append(torch.cuda.memory_allocated())
+    finally:
+        gc.enable()
+    assert used[3] <= used[1] + (1 << 20), used       # a leaked step would add the whole activation tape
+
+
+def test_fused_clip_equals_clip_then_step(gpu):
+    """FusedAdamW(max_grad_norm=...) == training.clip_grad_norm_ followed by torch.optim.AdamW, two steps."""
+    torch.manual_seed(0)
+    shapes = [(64, 3, 7, 7), (64,), (128, 64, 3, 3), (1000, 37), (5,)]
+    pa = [torch.nn.Parameter(torch.randn(*s, device=gpu)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = training.FusedAdamW(pa, lr=1e-3, weight_decay=0.01, max_grad_norm=2.0)
+    ob = torch.optim.AdamW(pb, lr=1e-3, weight_decay=0.01)
+    for it in range(2):
+        grads = [torch.randn(*s, device=gpu) * (3.0 if it == 0 else 0.001) for s in shapes]   # clipped, then not clipped
+        for p, q, g in zip(pa, pb, grads):
+            p.grad, q.grad = g.clone(), g.clone()
+        ref_norm = training.clip_grad_norm_(pb, 2.0)
+        versions = [p._version for p in pa]
+        oa.step()
+        ob.step()
+        assert abs(float(oa.last_grad_norm) - float(ref_norm)) <= 1e-5 * float(ref_norm)
+        assert all(p._version > v for p, v in zip(pa, versions))
+        for p, q in zip(pa, pb):
+            assert p.shape == q.shape and rel_err(p.detach().cpu(), q.detach().cpu()) <= 2e-6
+    sd = {str(i): p for i, p in enumerate(pa)}
+    assert all(t.is_contiguous() for t in sd.values())
+
+
 def test_eval_after_train_uses_new_weights(gpu):
     c, model, imgs, pts, boxes, labels = _train_case()
     model.eval()

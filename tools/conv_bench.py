@@ -12,12 +12,21 @@ SHAPES = {  # name: (N, H, W, Cin, Cout, k, stride, pad)
     "proj": (24, 57, 100, 256, 512, 1, 1, 0),
     "fusion1": (4, 128, 128, 512, 512, 3, 1, 1),
     "head": (4, 128, 128, 256, 320, 3, 1, 1),
+    "pn_fwd": (8, 1, 35000, 256, 1024, 1, 1, 0),
+    "pn_fwd_sq": (8, 175, 200, 256, 1024, 1, 1, 0),
+    "pn_dgrad": (8, 1, 35000, 1024, 256, 1, 1, 0),
+    "pn3": (8, 1, 35000, 128, 256, 1, 1, 0),
+    "sq1k": (8, 175, 200, 1024, 256, 1, 1, 0),
+    "l1_k2": (24, 225, 400, 128, 64, 3, 1, 1),
+    "l1_k4": (24, 225, 400, 256, 64, 3, 1, 1),
+    "l1_n2": (24, 225, 400, 64, 128, 3, 1, 1),
     "layer1_b1": (6, 225, 400, 64, 64, 3, 1, 1),
     "layer3_b1": (6, 57, 100, 256, 256, 3, 1, 1),
 }
 dev = torch.device("cuda")
 names = sys.argv[1].split(",") if len(sys.argv) > 1 else list(SHAPES)
 tiles = [int(t) for t in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1, 2, 3, 4]
+PLAIN = len(sys.argv) > 3 and sys.argv[3] == "plain"      # no scale/shift/relu epilogue
 for name in names:
     N, H, W, Cin, Cout, k, s, p = SHAPES[name]
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
@@ -29,15 +38,15 @@ for name in names:
     res = []
     for t in tiles:
         try:
-            for _ in range(2):
-                L.conv2d_nhwc(x, w, sc, sh, y, N=N, H=H, W=W, Cin=Cin, x_cs=Cin, Cout=Cout, y_cs=Cout, KH=k, KW=k, stride=s, pad=p, relu=True, tile=t)
+            for _ in range(8):
+                L.conv2d_nhwc(x, w, None if PLAIN else sc, None if PLAIN else sh, y, N=N, H=H, W=W, Cin=Cin, x_cs=Cin, Cout=Cout, y_cs=Cout, KH=k, KW=k, stride=s, pad=p, relu=not PLAIN, tile=t)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(5):
-                L.conv2d_nhwc(x, w, sc, sh, y, N=N, H=H, W=W, Cin=Cin, x_cs=Cin, Cout=Cout, y_cs=Cout, KH=k, KW=k, stride=s, pad=p, relu=True, tile=t)
+            for _ in range(10):
+                L.conv2d_nhwc(x, w, None if PLAIN else sc, None if PLAIN else sh, y, N=N, H=H, W=W, Cin=Cin, x_cs=Cin, Cout=Cout, y_cs=Cout, KH=k, KW=k, stride=s, pad=p, relu=not PLAIN, tile=t)
             e1.record(); torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 5
+            ms = e0.elapsed_time(e1) / 10
             res.append(f"tile{t}: {ms*1e3:7.1f}us {flops/ms/1e9:6.1f}TF")
         except Exception as ex:
             res.append(f"tile{t}: ERR {str(ex)[:40]}")
