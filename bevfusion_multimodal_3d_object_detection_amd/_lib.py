@@ -120,7 +120,8 @@ SIGNATURES = {
     "bevf_expand_border_classes_bf16": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 5 + [C.c_void_p]),
     "bevf_head_tail_bf16": (C.c_int, [C.POINTER(HeadDesc), C.c_void_p]),
     # ---- training step ----
-    "bevf_conv_pixtab": (C.c_int, [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]),
+    "bevf_conv_pixtab_bytes": (C.c_size_t, [C.c_int] * 7),
+    "bevf_conv_pixtab": (C.c_int, [C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
     "bevf_conv2d_wgrad_f32": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
     "bevf_zero_stuff_nhwc_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 7 + [C.c_void_p]),
     "bevf_bn_work_floats": (C.c_size_t, [C.c_int]),

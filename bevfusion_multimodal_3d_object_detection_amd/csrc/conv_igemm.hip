@@ -186,15 +186,20 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const i
     constexpr int buf = decltype(bufc)::value;
     constexpr bool first = decltype(firstc)::value;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 a[MI], b[NI];
+    f32x4 a[MI], b[NI], an[MI], bn[NI];
+    auto rd = [&](int g, f32x4 (&fa)[MI], f32x4 (&fb)[NI]) {
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
-        a[mi] = *reinterpret_cast<const f32x4*>(ldsb + a_rd[g] + buf * A_BYTES + mi * 4096);
+        fa[mi] = *reinterpret_cast<const f32x4*>(ldsb + a_rd[g] + buf * A_BYTES + mi * 4096);
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
-        b[ni] = *reinterpret_cast<const f32x4*>(ldsb + b_rd[g] + buf * B_BYTES + ni * 4096);
+        fb[ni] = *reinterpret_cast<const f32x4*>(ldsb + b_rd[g] + buf * B_BYTES + ni * 4096);
+    };
+    rd(0, a, b);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (g < 3) rd(g + 1, an, bn);                 // fragments of the next k-group in flight under this group's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
       if constexpr (kF32) {
 #pragma unroll
         for (int s = 0; s < 4; ++s)
@@ -212,6 +217,12 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const i
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[mi]),
                                                                   __builtin_bit_cast(bf16x8, b[ni]),
                                                                   first && g == 0 ? zero : acc[mi][ni], 0, 0, 0);
+      }
+      if (g < 3) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) a[mi] = an[mi];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b[ni] = bn[ni];
       }
     }
   };
@@ -231,7 +242,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const i
   if (KT >= 2) {                                    // peeled first pair: the first MFMA starts the accumulators
     advance();
     load_tile(1);
+    __builtin_amdgcn_sched_barrier(0);              // keep the global loads AHEAD of the MFMAs that hide them
     compute(B0{}, First{});
+    __builtin_amdgcn_sched_barrier(0);
     store_tile(B1{});
     __syncthreads();
     const bool more = 2 < KT;
@@ -239,7 +252,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const i
       advance();
       load_tile(2);
     }
+    __builtin_amdgcn_sched_barrier(0);
     compute(B1{}, Later{});
+    __builtin_amdgcn_sched_barrier(0);
     if (more) store_tile(B0{});
     __syncthreads();
     kt = 2;
@@ -251,7 +266,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const i
   for (; kt + 2 <= KT; kt += 2) {
     advance();
     load_tile(kt + 1);
+    __builtin_amdgcn_sched_barrier(0);
     compute(B0{}, Later{});
+    __builtin_amdgcn_sched_barrier(0);
     store_tile(B1{});
     __syncthreads();
     const bool more = kt + 2 < KT;
@@ -259,7 +276,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const i
       advance();
       load_tile(kt + 2);
     }
+    __builtin_amdgcn_sched_barrier(0);
     compute(B1{}, Later{});
+    __builtin_amdgcn_sched_barrier(0);
     if (more) store_tile(B0{});
     __syncthreads();
   }

@@ -44,13 +44,12 @@ def _zeros(n: int, dev, dtype=torch.float32) -> torch.Tensor:
 _PIXTAB: Dict[tuple, torch.Tensor] = {}
 
 
-def _pixtab(N, H, W, k, stride, pad, dev) -> torch.Tensor:
-    key = (N, H, W, k, stride, pad, str(dev))
+def _pixtab(N, H, W, k, stride, pad, x_cs, dev) -> torch.Tensor:
+    key = (N, H, W, k, stride, pad, x_cs, str(dev))
     t = _PIXTAB.get(key)
     if t is None:
-        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-        t = torch.empty(N * Ho * Wo * 2, dtype=torch.int32, device=dev)
-        _ck(_lib().bevf_conv_pixtab(t.data_ptr(), N, H, W, k, k, stride, pad, _st()), "bevf_conv_pixtab")
+        t = torch.empty(_lib().bevf_conv_pixtab_bytes(N, H, W, k, k, stride, pad) // 4, dtype=torch.int32, device=dev)
+        _ck(_lib().bevf_conv_pixtab(t.data_ptr(), N, H, W, k, k, stride, pad, x_cs, _st()), "bevf_conv_pixtab")
         _PIXTAB[key] = t
     return t
 
@@ -70,7 +69,7 @@ def conv_wgrad(x, dy, N, H, W, cin, cout, k, stride, pad, dw=None) -> torch.Tens
     """Returns dW in OHWI layout [cout][k][k][cin] (accumulates into `dw` when given)."""
     if dw is None:
         dw = _zeros(cout * k * k * cin, x.device)
-    d = L.WgradDesc(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _pixtab(N, H, W, k, stride, pad, x.device).data_ptr(),
+    d = L.WgradDesc(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _pixtab(N, H, W, k, stride, pad, cin, x.device).data_ptr(),
                     N, H, W, cin, cin, cout, cout, k, k, stride, pad)
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     with E._span("conv_wgrad_f32", flops=2.0 * N * Ho * Wo * cout * k * k * cin):

@@ -270,8 +270,11 @@ int bevf_head_tail_bf16(const bevf_head_desc* d, void* stream);          /* hid 
  * (conv weight gradient, bilinear / gather-L1 scatter) are not bitwise reproducible run to run.
  * ========================================================================================== */
 
-/* Pixel table for the weight gradient: tab[m] = {n*H*W, (ih0<<16)|(iw0&0xffff)}, 2 x int32 per output pixel. */
-int bevf_conv_pixtab(int32_t* tab, int N, int H, int W, int KH, int KW, int stride, int pad, void* stream);
+/* Tap table for the weight gradient: tab[m][t] = byte offset of x[n][ih][iw][0] under filter tap t of output pixel
+ * m (0x80000000 for padding taps and for the rows that pad M up to a multiple of 32); depends on the shape and on
+ * x_cs only, so callers cache it.  bevf_conv_pixtab_bytes = size of the table.                                   */
+size_t bevf_conv_pixtab_bytes(int N, int H, int W, int KH, int KW, int stride, int pad);
+int bevf_conv_pixtab(int32_t* tab, int N, int H, int W, int KH, int KW, int stride, int pad, int x_cs, void* stream);
 
 /* dW[co][kh][kw][ci] += sum_m dy[m][co] * x[pixel(m)+tap][ci]   (dw zero-filled by the caller; OHWI like the
  * forward weights; the host permutes back to the parameter's OIHW).  MFMA fp32, pixel range split over WGs. */
@@ -279,7 +282,7 @@ typedef struct {
   const float* x;          /* [N][H][W][x_cs] forward input */
   const float* dy;         /* [N*Ho*Wo][dy_cs] gradient of the raw conv output */
   float* dw;               /* [Cout][KH][KW][Cin] */
-  const int32_t* pixtab;
+  const int32_t* pixtab;   /* bevf_conv_pixtab for this shape and x_cs */
   int32_t N, H, W, Cin, x_cs, Cout, dy_cs, KH, KW, stride, pad;
 } bevf_wgrad_desc;
 int bevf_conv2d_wgrad_f32(const bevf_wgrad_desc* d, void* stream);
