@@ -17,7 +17,11 @@
 // (holding the h shift) + compile-time immediate", fully unrolled: 3 ds_read_b32 + 2 MFMA per step.
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TP = 128;              // output pixels per workgroup row (along W)
 constexpr int TH = 4;                // output rows per workgroup
@@ -55,23 +59,41 @@ __global__ __launch_bounds__(256) void stem_conv7x7(const float* __restrict__ x,
   const int n = blockIdx.x / (tilesW * tilesH);
   const int ow0 = tw * TP, oh0 = th * TH;
 
+  // Staging is written for a minimal VALU count (every vector-ALU instruction here queues behind the other
+  // workgroup's 64-cycle MFMAs): per-lane offsets are computed once, rows advance on the scalar unit.
   // filter bank, pre-packed by the host as [k = c*49+kh*7+kw][co] with a zero row k = 147
-#pragma unroll 5
-  for (int i = tid; i < KPAD * 16; i += 256)
-    reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(w)[i];
+  {
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, KPAD * 64 * 4, 0x00020000);
+    const unsigned voff = (unsigned)tid * 16u;
+#pragma unroll
+    for (int it = 0; it < (KPAD * 16 + 255) / 256; ++it) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, voff, it * 4096, 0);
+      if (it * 256 + 255 < KPAD * 16 || tid < KPAD * 16 - it * 256)
+        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(wl) + tid * 16 + it * 4096) = v;
+    }
+  }
   // patch row (c, pr) <-> image row ih = 2*oh0 - 3 + pr of plane c; patch col <-> iw = 2*ow0 - 4 + col
   const float* img = x + (size_t)n * 3 * H * W;
   const int iw0 = 2 * ow0 - 4;
   if (vec_ok) {                          // W % 4 == 0 and 16-B aligned rows: whole float4s are in or out
-#pragma unroll 4
-    for (int i = tid; i < 3 * PR * (PW / 4); i += 256) {
-      const int r = i / (PW / 4), c4 = i - r * (PW / 4);
+    // one patch row per wave and pass: lane -> float4 column (66 per row: lanes 0,1 take a second one)
+    const int iwa = iw0 + 4 * lane, iwb = iw0 + 4 * (lane + 64);
+    const unsigned va = (unsigned)iwa < (unsigned)W ? (unsigned)(iwa * 4) : 0x80000000u;
+    const unsigned vb = (lane < 2 && (unsigned)iwb < (unsigned)W) ? (unsigned)(iwb * 4) : 0x80000000u;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    for (int r = wv; r < 3 * PR; r += 4) {
       const int c = r / PR, pr = r - c * PR;
-      const int ih = 2 * oh0 - 3 + pr, iw = iw0 + 4 * c4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
-        v = *reinterpret_cast<const f32x4*>(img + ((size_t)c * H + ih) * W + iw);
-      reinterpret_cast<f32x4*>(patch)[i] = v;
+      const int ih = 2 * oh0 - 3 + pr;
+      char* const dst = reinterpret_cast<char*>(patch) + r * (PW * 4) + lane * 16;
+      u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
+      if ((unsigned)ih < (unsigned)H) {             // wave-uniform
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(img) + ((size_t)c * H + ih) * W, 0, W * 4, 0x00020000);
+        v0 = __builtin_amdgcn_raw_buffer_load_b128(rx, va, 0, 0);
+        v1 = __builtin_amdgcn_raw_buffer_load_b128(rx, vb, 0, 0);
+      }
+      *reinterpret_cast<u32x4*>(dst) = v0;
+      if (lane < 2) *reinterpret_cast<u32x4*>(dst + 1024) = v1;
     }
   } else {
 #pragma unroll 8
@@ -87,6 +109,8 @@ __global__ __launch_bounds__(256) void stem_conv7x7(const float* __restrict__ x,
 
   const int h = lane >> 5, l31 = lane & 31;
   const int pix = wave * 32 + l31;             // pixel within the tile row
+  const int wv32 = __builtin_amdgcn_readfirstlane(wave) * 32;
+  const unsigned y_lane = (unsigned)((4 * h * 64 + l31) * (int)sizeof(TO)), y_lane2 = y_lane + 4096u;
   const float sc0 = scale[l31], sh0 = shift[l31], sc1 = scale[l31 + 32], sh1 = shift[l31 + 32];
   const char* const bb = reinterpret_cast<const char*>(wl) + l31 * 4;
   const char* const pb[3] = {bb + h * 7 * 256, bb + h * 256, bb + h * 49 * 256};
@@ -96,9 +120,8 @@ __global__ __launch_bounds__(256) void stem_conv7x7(const float* __restrict__ x,
     if (oh >= Ho) break;
     const char* const ab = reinterpret_cast<const char*>(patch) + (2 * ro * PW + 2 * pix) * 4;
     const char* const pa[4] = {ab + h * PW * 4, ab + h * 4, ab + h * PR * PW * 4, ab};
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    f32x16 acc0, acc1;                               // started by the first MFMA (C = 0)
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // software pipeline over chunks of 4 steps: the 12 operand reads of chunk c+1 are issued before
     // the 8 MFMAs of chunk c (two register sets, statically indexed), so LDS latency hides under MFMA
     constexpr int CH = 4, NCH = (NSTEP + CH - 1) / CH;
@@ -124,59 +147,77 @@ __global__ __launch_bounds__(256) void stem_conv7x7(const float* __restrict__ x,
 #pragma unroll
       for (int u = 0; u < CH; ++u) {
         if (c * CH + u < NSTEP) {
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c & 1][u], b0v[c & 1][u], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c & 1][u], b1v[c & 1][u], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c & 1][u], b0v[c & 1][u], c == 0 && u == 0 ? zero : acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c & 1][u], b1v[c & 1][u], c == 0 && u == 0 ? zero : acc1, 0, 0, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    // epilogue: column j = lane&31 -> channel, row i -> pixel wave*32 + i
-    TO* yrow = y + ((size_t)(n * Ho + oh) * Wo + ow0) * 64;
+    // epilogue: column j = lane&31 -> channel, row i -> pixel wave*32 + i.  Buffer stores: the lane offset is fixed,
+    // the pixel offsets are instruction immediates, and pixels past the end of the row fall outside the descriptor.
+    TO* const ywave = y + ((size_t)(n * Ho + oh) * Wo + ow0 + wv32) * 64;
+    const int left = Wo - ow0 - wv32;                 // pixels of this wave's 32 that exist
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        ywave, 0, left > 0 ? (left > 32 ? 32 : left) * 64 * (int)sizeof(TO) : 0, 0x00020000);
+    // (two lane bases so that every pixel offset fits the 12-bit instruction immediate, which -- unlike the scalar
+    // offset -- takes part in the descriptor's range check)
+    constexpr int ES = (int)sizeof(TO);
+    auto put = [&](auto relu_c) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (ow0 + i < Wo) {
-        const float v0 = fmaf(acc0[r], sc0, sh0), v1 = fmaf(acc1[r], sc1, sh1);
-        yrow[(size_t)i * 64 + l31] = (TO)(relu ? fmaxf(v0, 0.f) : v0);
-        yrow[(size_t)i * 64 + l31 + 32] = (TO)(relu ? fmaxf(v1, 0.f) : v1);
+      for (int r = 0; r < 16; ++r) {
+        const int ioff = ((r & 3) + 8 * (r >> 2)) * 64 * ES;
+        const unsigned base = ioff < 4096 - 32 * ES ? y_lane : y_lane2;
+        const int imm = ioff < 4096 - 32 * ES ? ioff : ioff - 4096;
+        float v0 = fmaf(acc0[r], sc0, sh0), v1 = fmaf(acc1[r], sc1, sh1);
+        if constexpr (decltype(relu_c)::value) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+        if constexpr (sizeof(TO) == 4) {
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), ry, base + imm, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), ry, base + imm + 32 * ES, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)v0), ry, base + imm, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)v1), ry, base + imm + 32 * ES, 0, 0);
+        }
       }
-    }
+    };
+    if (relu) put(std::true_type{}); else put(std::false_type{});
   }
 }
 
 constexpr size_t kStemLds = (size_t)(KPAD * 64 + 3 * PR * PW) * sizeof(float);
 
 // 3x3 stride-2 pad-1 max-pool on NHWC, one 16-byte channel vector per thread.  ref src/encoders.py:157.
+// Neighbouring output rows share an input row; the workgroups are renumbered so that each XCD (own L2) owns a
+// contiguous band of output rows and fetches the shared rows from HBM once.
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W,
                                                           int C, int Ho, int Wo) {
   constexpr int V = vec16<T>::N;
   const int cv = C / V;
   const long long total = (long long)N * Ho * Wo * cv;
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % cv);
-    long long pix = i / cv;
-    const int ow = (int)(pix % Wo);
-    pix /= Wo;
-    const int oh = (int)(pix % Ho), n = (int)(pix / Ho);
-    float m[V], v[V];
+  const long long i = (long long)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % cv);
+  long long pix = i / cv;
+  const int ow = (int)(pix % Wo);
+  pix /= Wo;
+  const int oh = (int)(pix % Ho), n = (int)(pix / Ho);
+  float m[V], v[V];
 #pragma unroll
-    for (int j = 0; j < V; ++j) m[j] = -INFINITY;
+  for (int j = 0; j < V; ++j) m[j] = -INFINITY;
 #pragma unroll
-    for (int dh = 0; dh < 3; ++dh) {
-      const int ih = 2 * oh - 1 + dh;
-      if ((unsigned)ih >= (unsigned)H) continue;
+  for (int dh = 0; dh < 3; ++dh) {
+    const int ih = 2 * oh - 1 + dh;
+    if ((unsigned)ih >= (unsigned)H) continue;
 #pragma unroll
-      for (int dw = 0; dw < 3; ++dw) {
-        const int iw = 2 * ow - 1 + dw;
-        if ((unsigned)iw >= (unsigned)W) continue;
-        load16(x + ((size_t)(n * H + ih) * W + iw) * C + c * V, v);
+    for (int dw = 0; dw < 3; ++dw) {
+      const int iw = 2 * ow - 1 + dw;
+      if ((unsigned)iw >= (unsigned)W) continue;
+      load16(x + ((size_t)(n * H + ih) * W + iw) * C + c * V, v);
 #pragma unroll
-        for (int j = 0; j < V; ++j) m[j] = fmaxf(m[j], v[j]);
-      }
+      for (int j = 0; j < V; ++j) m[j] = fmaxf(m[j], v[j]);
     }
-    store16(y + (size_t)i * V, m);
   }
+  store16(y + (size_t)i * V, m);
 }
 
 }  // namespace
@@ -220,7 +261,8 @@ static int maxpool_entry(const void* x, void* y, int N, int H, int W, int C, voi
   BEVF_REQUIRE(bevf_aligned16(x) && bevf_aligned16(y), "maxpool: unaligned");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const long long total = (long long)N * Ho * Wo * (C / V);
-  const unsigned grid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  BEVF_REQUIRE((total + 255) / 256 < (1ll << 31), "maxpool: grid too large");
+  const unsigned grid = (unsigned)((total + 255) / 256);
   hipLaunchKernelGGL(maxpool3x3s2_nhwc<T>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<const T*>(x), static_cast<T*>(y), N, H, W, C, Ho, Wo);
   return bevf_check_launch("bevf_maxpool3x3s2_nhwc");
