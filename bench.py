@@ -112,8 +112,10 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="train = BASELINE config 4: fwd + targets + loss + bwd + grad all-reduce + clip + AdamW")
-    ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32",
-                    help="storage dtype of weights/activations (bf16 = BASELINE configs 3/5: bf16 storage, fp32 accumulate)")
+    ap.add_argument("--dtype", choices=["fp32", "bf16", "f32x3"], default="fp32",
+                    help="fp32 (default): exact fp32 MFMA.  bf16 = BASELINE configs 3/5: bf16 storage, fp32 accumulate.  "
+                         "f32x3: fp32 storage, convolutions through an exact 3-way bf16 split on the bf16 MFMA "
+                         "(fp32-level error, not bit-identical to fp32; opt-in, never the headline)")
     ap.add_argument("--graph", action="store_true", help="replay the inference forward as one hipGraph (small batches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true", help="skip the per-launch HIP-event brackets")
@@ -137,6 +139,10 @@ def main():
     model_cpu = build_model(cfg)
     state = {k: v.clone() for k, v in model_cpu.state_dict().items()}
     model = model_cpu.to(dev)
+    if args.dtype == "f32x3":
+        if args.mode == "train":
+            raise SystemExit("training runs in exact fp32")
+        engine.set_conv_mode("f32x3")
     if args.dtype == "bf16":
         if args.mode == "train":
             raise SystemExit("training runs in fp32 (the reference has no mixed precision, SURVEY.md 5)")
@@ -215,8 +221,11 @@ def main():
                         conv = {k: conv[k] + e[k] for k in conv}
             if conv:
                 ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
-                peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "fp32" else PEAK_BF16_MFMA_TFLOPS
-                line["roofline"] = {"kernel": "conv_igemm_f32" if args.mode == "infer" else "conv_igemm_f32+conv_wgrad_f32",
+                # f32x3 spends six bf16 MFMA products per algorithmic multiply-add: its ceiling is a sixth of the bf16 peak
+                peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS,
+                        "f32x3": PEAK_BF16_MFMA_TFLOPS / 6.0}[args.dtype]
+                kname = {"fp32": "conv_igemm_f32", "bf16": "conv_igemm_bf16", "f32x3": "conv_split_f32x3"}[args.dtype]
+                line["roofline"] = {"kernel": kname if args.mode == "infer" else "conv_igemm_f32+conv_wgrad_f32",
                                     "bound": "mfma", "achieved": ach,
                                     "traffic_source": None,
                                     "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,

@@ -109,6 +109,8 @@ SIGNATURES = {
     "bevf_voxelize_work_bytes": (C.c_size_t, [C.c_int] * 2),
     "bevf_voxelize_f32": (C.c_int, [C.POINTER(VoxelizeDesc), C.c_void_p]),
     # ---- bf16 storage path ----
+    "bevf_split_weights_f32x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "bevf_conv2d_nhwc_f32x3": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "bevf_conv2d_nhwc_bf16": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "bevf_stem_conv7x7_bf16out": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_maxpool3x3s2_nhwc_bf16": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
@@ -210,8 +212,9 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, scale, shift, y: Optional[torc
     M = N * Ho * Wo
     if x.numel() < (N * H * W - 1) * x_cs + Cin:
         raise BevfError("conv: input buffer smaller than N*H*W*x_cs")
-    if w.numel() != Cout * KH * KW * Cin:
-        raise BevfError(f"conv: packed weight has {w.numel()} elements, expected {Cout * KH * KW * Cin}")
+    split = x.dtype == torch.float32 and w.dtype == torch.bfloat16      # f32x3: planes from split_weights_f32x3
+    if w.numel() != Cout * KH * KW * Cin * (3 if split else 1):
+        raise BevfError(f"conv: packed weight has {w.numel()} elements, expected {Cout * KH * KW * Cin * (3 if split else 1)}")
     if y is not None and y.numel() < (M - 1) * y_cs + Cout:
         raise BevfError("conv: output buffer too small")
     if res is not None and res.numel() < (M - 1) * res_cs + Cout:
@@ -222,10 +225,18 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, scale, shift, y: Optional[torc
     if colmax is not None and colmax.numel() < -(-M // rows_per_group) * Cout:
         raise BevfError("conv: colmax buffer too small")
     dt = x.dtype
-    d = ConvDesc(_p(x, dt), _pc(w, dt), _pc(scale), _pc(shift), _p(res, dt), _p(y, dt), _pc(colmax, torch.int32),
+    d = ConvDesc(_p(x, dt), _pc(w, w.dtype), _pc(scale), _pc(shift), _p(res, dt), _p(y, dt), _pc(colmax, torch.int32),
                  N, H, W, Cin, x_cs, Ho, Wo, Cout, y_cs, res_cs, KH, KW, stride, pad, int(relu), rows_per_group, tile)
-    fn = "bevf_conv2d_nhwc_" + _sfx(x)
+    fn = "bevf_conv2d_nhwc_f32x3" if split else "bevf_conv2d_nhwc_" + _sfx(x)
     _check(getattr(lib(), fn)(C.byref(d), _stream()), fn)
+
+
+def split_weights_f32x3(w: torch.Tensor) -> torch.Tensor:
+    """fp32 packed filter -> [3][n] bf16 planes (hi, mid, lo) for the f32x3 convolution."""
+    w = w.contiguous()
+    out = torch.empty(3 * w.numel(), dtype=torch.bfloat16, device=w.device)
+    _check(lib().bevf_split_weights_f32x3(_pc(w), _p(out, torch.bfloat16), w.numel(), _stream()), "bevf_split_weights_f32x3")
+    return out
 
 
 def stem_conv7x7(x: torch.Tensor, w_packed: torch.Tensor, scale, shift, y: torch.Tensor, N: int, H: int, W: int,

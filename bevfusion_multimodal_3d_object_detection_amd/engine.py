@@ -45,8 +45,28 @@ class PackedConv:
     relu: bool
 
 
-def pack_conv(conv, bn=None, relu: bool = True) -> PackedConv:
-    """Weights keep the module's storage dtype (fp32 or bf16); the folded BN scale/shift are always fp32."""
+_CONV_MODE = "f32"
+
+
+def set_conv_mode(mode: str) -> None:
+    """How fp32 models multiply in their convolutions.  "f32" (default): v_mfma_f32_32x32x2_f32, an exact fp32 FMA
+    chain.  "f32x3": opt-in, fp32 operands split exactly into three bf16 planes and multiplied on the bf16 MFMA
+    (six partial products, fp32 accumulate; csrc/conv_split.hip) -- fp32-level error, ~1.3-1.4x faster, not
+    bit-identical to the default.  Engines repack on the next forward."""
+    global _CONV_MODE
+    if mode not in ("f32", "f32x3"):
+        raise ValueError(f"conv mode must be 'f32' or 'f32x3', got {mode!r}")
+    _CONV_MODE = mode
+
+
+def conv_mode() -> str:
+    return _CONV_MODE
+
+
+def pack_conv(conv, bn=None, relu: bool = True, split_ok: bool = True) -> PackedConv:
+    """Weights keep the module's storage dtype (fp32 or bf16); the folded BN scale/shift are always fp32.
+    In "f32x3" mode fp32 filters with Cin % 32 == 0 are stored as three bf16 planes (split_ok=False: layers whose
+    launch needs what the f32x3 kernel lacks, i.e. the fused column max)."""
     w = conv.weight.detach()
     if w.dim() == 3:                                   # Conv1d k=1 == pointwise
         w = w.unsqueeze(-1)
@@ -55,7 +75,10 @@ def pack_conv(conv, bn=None, relu: bool = True) -> PackedConv:
     stride = conv.stride[0] if isinstance(conv.stride, tuple) else conv.stride
     pad = conv.padding[0] if isinstance(conv.padding, tuple) else conv.padding
     scale, shift = _bn_fold(conv.bias, bn, cout, w.device)
-    return PackedConv(w.permute(0, 2, 3, 1).contiguous().view(-1), scale, shift, cin, cout, kh, stride, pad, relu)
+    packed = w.permute(0, 2, 3, 1).contiguous().view(-1)
+    if _CONV_MODE == "f32x3" and split_ok and packed.dtype == torch.float32 and cin % 32 == 0:
+        packed = L.split_weights_f32x3(packed)
+    return PackedConv(packed, scale, shift, cin, cout, kh, stride, pad, relu)
 
 
 def _check_eval(module: nn.Module) -> None:
@@ -75,7 +98,7 @@ class _Engine:
         self._bufs: Dict[str, torch.Tensor] = {}
 
     def _signature(self):
-        return tuple((t.data_ptr(), t._version) for t in self.module.state_dict(keep_vars=True).values())
+        return (_CONV_MODE,) + tuple((t.data_ptr(), t._version) for t in self.module.state_dict(keep_vars=True).values())
 
     def ensure_packed(self) -> None:
         sig = self._signature()
@@ -237,7 +260,8 @@ class PointNetEngine(_Engine):
         self.w0 = w0.reshape(w0.shape[0], self.cin).float().contiguous()
         self.s0, self.b0 = _bn_fold(convs[0].bias, bns[0], w0.shape[0], w0.device)
         self.c0 = w0.shape[0]
-        self.layers = [pack_conv(c, b, True) for c, b in zip(convs[1:], bns[1:])]
+        n = len(convs) - 1                            # the last layer fuses the max over points (colmax): exact kernel
+        self.layers = [pack_conv(c, b, True, split_ok=i < n - 1) for i, (c, b) in enumerate(zip(convs[1:], bns[1:]))]
 
     def run(self, pts: torch.Tensor, keep_last: bool = False):
         """pts: (B,N,C) contiguous -> (B, feat) global max feature [and the (B*N, feat) last activations]."""

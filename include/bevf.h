@@ -250,6 +250,13 @@ int bevf_voxelize_f32(const bevf_voxelize_desc* d, void* stream);
  * fp32.  bevf_conv2d_nhwc_bf16 takes the same descriptor with x / w / res / y pointing at bf16 data.
  * ========================================================================================== */
 int bevf_conv2d_nhwc_bf16(const bevf_conv_desc* d, void* stream);
+
+/* Opt-in "f32x3" convolution: same contract as bevf_conv2d_nhwc_f32 (fp32 activations in and out, no colmax), but
+ * the products run on the bf16 MFMA over an exact three-way bf16 split of both operands (six partial products,
+ * fp32 accumulate): fp32-level error, not bit-identical to the fp32 FMA chain.  `w` = planes written by
+ * bevf_split_weights_f32x3: [3][Cout][KH][KW][Cin] bf16 (hi, mid, lo).  tile: 0 auto, 1 / 3 / 4 as above.      */
+int bevf_split_weights_f32x3(const float* w, void* planes, size_t n, void* stream);
+int bevf_conv2d_nhwc_f32x3(const bevf_conv_desc* d, void* stream);
 int bevf_stem_conv7x7_bf16out(const float* x, const float* w, const float* scale, const float* shift, void* y, int N,
                               int H, int W, int relu, void* stream);     /* fp32 image + fp32 MFMA, bf16 NHWC out */
 int bevf_maxpool3x3s2_nhwc_bf16(const void* x, void* y, int N, int H, int W, int C, void* stream);

@@ -27,12 +27,14 @@ dev = torch.device("cuda")
 names = sys.argv[1].split(",") if len(sys.argv) > 1 else list(SHAPES)
 tiles = [int(t) for t in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1, 2, 3, 4]
 PLAIN = len(sys.argv) > 3 and sys.argv[3] == "plain"      # no scale/shift/relu epilogue
+SPLIT = len(sys.argv) > 3 and sys.argv[3] == "split"      # f32x3 kernel
 for name in names:
     N, H, W, Cin, Cout, k, s, p = SHAPES[name]
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
     x = torch.randn(N * H * W * Cin, device=dev)
     w = torch.randn(Cout * k * k * Cin, device=dev) * 0.05
     sc, sh = torch.rand(Cout, device=dev) + 0.5, torch.randn(Cout, device=dev)
+    if SPLIT: w = L.split_weights_f32x3(w)
     y = torch.empty(N * Ho * Wo * Cout, device=dev)
     flops = 2.0 * N * Ho * Wo * Cout * k * k * Cin
     res = []
