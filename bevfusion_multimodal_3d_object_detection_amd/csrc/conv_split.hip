@@ -7,7 +7,10 @@
 //     hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi          (dropped: mid*lo, lo*mid, lo*lo ~ 2^-24 |a*b|)
 // so the result carries fp32-level error (measured against fp64 next to the exact-fp32 kernel in
 // tests/test_gpu_split.py) without being bit-identical to an fp32 FMA chain.  It is an OPT-IN mode
-// (model.conv_mode = "f32x3"); the default path stays exact fp32.
+// (engine.set_conv_mode("f32x3")); the default path stays exact fp32.
+// Measured (MI355X, random data): 195-210 TF algorithmic on the 3x3 layers vs 135-146 for the exact kernel.  Halving the
+// MFMA count in a what-if build showed the six products alone take ~2/3 of the time at ~1.77 PFLOP/s bf16 -- the chip
+// holds ~1.7 GHz under this load -- so the scheme's ceiling is ~295 TF; the rest is staging (the split costs ~12 %).
 //
 // Activations stay fp32 in HBM and are split while they are staged into LDS (about 26 vector-ALU instructions per
 // 4 elements; the bf16 MFMA leaves most of the vector issue slots free, unlike the fp32 MFMA).  Weights are split

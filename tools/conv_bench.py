@@ -4,6 +4,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bevfusion_multimodal_3d_object_detection_amd import _lib as L
+if os.environ.get("BEVF_AB_LIB"): L.LIB_PATH = os.environ["BEVF_AB_LIB"]
 
 SHAPES = {  # name: (N, H, W, Cin, Cout, k, stride, pad)
     "layer1": (24, 225, 400, 64, 64, 3, 1, 1),
