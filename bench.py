@@ -159,13 +159,15 @@ def main():
         # ref train_detect.py:725-741 (AdamW lr 1e-4 wd 0.01) and :431 (clip_grad_norm_ 10), clip folded into the update
         opt = training.FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.01, max_grad_norm=10.0)
 
+        if dist is not None:          # DP: gradient all-reduce (RCCL) issued from inside the backward, overlapped with it
+            training.set_grad_reducer(replicas.GradReducer(dist))
+
         def step():
             pred = model(*inputs)
             tgt = ct.prepare_centernet_targets(gt, dev)
             losses = crit(pred, tgt)
             opt.zero_grad()
             losses["total_loss"].backward()
-            replicas.allreduce_gradients(model.parameters(), dist)                    # RCCL, DP only
             opt.step()
             return {k: v.detach() for k, v in losses.items()}
     elif args.graph:

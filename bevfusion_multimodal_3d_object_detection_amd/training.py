@@ -154,15 +154,32 @@ def add_(y, x, n):
 class GradSink:
     """Collects parameter gradients by parameter identity (summing repeated contributions)."""
 
-    def __init__(self):
+    def __init__(self, reducer=None):
         self.g: Dict[int, torch.Tensor] = {}
+        self.reducer = reducer               # replicas.GradReducer: averages gradients over the ranks while backward runs
+        self._sent = set()
 
     def add(self, p: Optional[torch.Tensor], g: torch.Tensor):
         if p is None or not p.requires_grad:
             return
         g = g.reshape(p.shape)
         k = id(p)
+        assert k not in self._sent, "gradient contribution after the parameter was handed to the all-reduce"
         self.g[k] = g if k not in self.g else self.g[k] + g
+
+    def ready(self):
+        """Every gradient collected so far is final: start its all-reduce now, under the rest of the backward."""
+        if self.reducer is None:
+            return
+        keys = [k for k in self.g if k not in self._sent]
+        if keys:
+            self.reducer.submit(self, keys)
+            self._sent.update(keys)
+
+    def finish(self):
+        if self.reducer is not None:
+            self.ready()
+            self.reducer.finish(self)
 
     def get(self, p):
         return self.g.get(id(p))
@@ -325,7 +342,7 @@ class DetectorTape:
     def _camera_backward(self, dfeat, sink):
         enc = self.m.camera_encoder
         d, _ = self.proj.backward(dfeat, sink)
-        for c1, c2, down in reversed(self.blocks):
+        for i, (c1, c2, down) in enumerate(reversed(self.blocks)):
             dt, d_res = c2.backward(d, sink)                   # d_res: gradient reaching the skip connection
             dx, _ = c1.backward(dt, sink)
             if down is not None:
@@ -334,6 +351,8 @@ class DetectorTape:
             else:
                 add_(dx, d_res, min(dx.numel(), d_res.numel()))
             d = dx
+            if i % 2 == 1:
+                sink.ready()                                   # one ResNet stage done: its gradients can travel
         N, H1, W1 = self.pool_geom
         dpool_in = _new(N * H1 * W1 * 64, d.device)
         _ck(_lib().bevf_maxpool3x3s2_bwd_f32(d.data_ptr(), self.pool_idx.data_ptr(), dpool_in.data_ptr(), N, H1, W1, 64, _st()),
@@ -568,9 +587,9 @@ class DetectorTape:
         self.S = (Sh, Sw)
         return outs
 
-    def backward(self, douts: List[torch.Tensor]) -> GradSink:
+    def backward(self, douts: List[torch.Tensor], reducer=None) -> GradSink:
         m = self.m
-        sink = GradSink()
+        sink = GradSink(reducer)
         B, (Sh, Sw) = self.B, self.S
         P = Sh * Sw
         dev = self.outs[0].device
@@ -636,8 +655,20 @@ class DetectorTape:
                 dfeat = _new(Bc * ncam * Pc * Cc, dev)
                 _ck(_lib().bevf_cam_mean_bwd_f32(dpooled.data_ptr(), dfeat.data_ptr(), Bc, ncam, Pc, Cc, _st()),
                     "bevf_cam_mean_bwd_f32")
+            sink.ready()              # head, fusion, radar, LiDAR (the 164 MB dense layer): reduce under the camera trunk
             self._camera_backward(dfeat, sink)
+        sink.finish()
         return sink
+
+
+_GRAD_REDUCER = None
+
+
+def set_grad_reducer(reducer) -> None:
+    """Data-parallel training: install a replicas.GradReducer and the detector's backward averages its gradients over
+    the ranks itself, bucket by bucket as they become final, overlapped with the rest of the backward (None: off)."""
+    global _GRAD_REDUCER
+    _GRAD_REDUCER = reducer
 
 
 class _DetectorTrainFn(torch.autograd.Function):
@@ -657,7 +688,7 @@ class _DetectorTrainFn(torch.autograd.Function):
         if ctx.tape is None:
             raise RuntimeError("Trying to backward through the detector a second time: its saved activations were freed")
         with torch.no_grad():
-            sink = ctx.tape.backward(list(douts))
+            sink = ctx.tape.backward(list(douts), _GRAD_REDUCER)
         ctx.tape = None                                   # activations are dead now: hand them back to the allocator
         grads = []
         for p in ctx.params:
