@@ -108,6 +108,10 @@ SIGNATURES = {
     "bevf_centernet_loss_f32": (C.c_int, [C.POINTER(LossDesc), C.c_void_p]),
     "bevf_voxelize_work_bytes": (C.c_size_t, [C.c_int] * 2),
     "bevf_voxelize_f32": (C.c_int, [C.POINTER(VoxelizeDesc), C.c_void_p]),
+    # ---- input pipeline ----
+    "bevf_resize_normalize_u8": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 5 + [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 2 +
+                                 [C.c_int] + [C.POINTER(C.c_float)] * 2 + [C.c_void_p]),
+    "bevf_lidar_filter_pad_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 3 + [C.POINTER(C.c_float), C.c_void_p]),
     # ---- bf16 storage path ----
     "bevf_split_weights_f32x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "bevf_conv2d_nhwc_f32x3": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),

@@ -1,0 +1,135 @@
+// Input pipeline on the device (ref src/train_detect.py:123-189).
+//
+// resize_normalize_u8: Pillow's antialiased bilinear resize (what torchvision's T.Resize does to a PIL image) in
+//   Pillow's own 22-bit fixed-point arithmetic -- horizontal pass rounded and clamped to uint8, then the vertical
+//   pass -- followed by ToTensor (/255) and Normalize ((t-mean)/std) in fp32, written planar (NCHW) for the stem.
+//   The per-axis tables (first source index, count, integer weights) come from the host
+//   (preprocess.resample_tables); the resized uint8 value is bit-identical to Pillow's.
+// lidar_filter_pad: range filter with strict inequalities, order-preserving compaction (wave ballot + block scan),
+//   zero padding / index gather to exactly max_points rows.
+#include "common.h"
+
+namespace {
+
+constexpr int kPrec = 32 - 8 - 2;
+
+__device__ __forceinline__ int clip8(int v) {
+  v >>= kPrec;
+  return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+__global__ __launch_bounds__(256) void resize_normalize_u8(const unsigned char* __restrict__ x, float* __restrict__ out,
+                                                            int n, int H, int W, int Ho, int Wo,
+                                                            const int* __restrict__ bh, const int* __restrict__ kh, int ksh,
+                                                            const int* __restrict__ bv, const int* __restrict__ kv, int ksv,
+                                                            float m0, float m1, float m2, float s0, float s1, float s2) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  const long long total = (long long)n * Ho * Wo;
+  if (i >= total) return;
+  const int ox = (int)(i % Wo);
+  const int oy = (int)((i / Wo) % Ho);
+  const int img = (int)(i / ((long long)Wo * Ho));
+  const int x0 = bh[2 * ox], nx = bh[2 * ox + 1], y0 = bv[2 * oy], ny = bv[2 * oy + 1];
+  const int* const kx = kh + (size_t)ox * ksh;
+  const int* const ky = kv + (size_t)oy * ksv;
+  const unsigned char* const base = x + (size_t)img * H * W * 3;
+  int v0 = 1 << (kPrec - 1), v1 = v0, v2 = v0;
+  for (int j = 0; j < ny; ++j) {
+    const unsigned char* row = base + ((size_t)(y0 + j) * W + x0) * 3;
+    int h0 = 1 << (kPrec - 1), h1 = h0, h2 = h0;
+    for (int t = 0; t < nx; ++t) {
+      const int k = kx[t];
+      h0 += (int)row[3 * t] * k;
+      h1 += (int)row[3 * t + 1] * k;
+      h2 += (int)row[3 * t + 2] * k;
+    }
+    const int k = ky[j];                              // the horizontal pass leaves a uint8 image
+    v0 += clip8(h0) * k;
+    v1 += clip8(h1) * k;
+    v2 += clip8(h2) * k;
+  }
+  const size_t plane = (size_t)Ho * Wo, o = (size_t)img * 3 * plane + (size_t)oy * Wo + ox;
+  out[o] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)clip8(v0), 255.f), m0), s0);
+  out[o + plane] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)clip8(v1), 255.f), m1), s1);
+  out[o + 2 * plane] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)clip8(v2), 255.f), m2), s2);
+}
+
+// one workgroup per sweep: flags -> exclusive scan in point order -> compacted rows in `work`; then the output rows
+__global__ __launch_bounds__(1024) void lidar_filter_pad(const float* __restrict__ pts, float* __restrict__ out,
+                                                          int* __restrict__ count, float* __restrict__ work,
+                                                          const long long* __restrict__ choice, int N, int C, int max_points,
+                                                          float x0, float y0, float z0, float x1, float y1, float z1) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < N; base += 1024) {
+    const int i = base + tid;
+    bool keep = false;
+    if (i < N) {
+      const float px = pts[(size_t)i * C], py = pts[(size_t)i * C + 1], pz = pts[(size_t)i * C + 2];
+      keep = px > x0 && px < x1 && py > y0 && py < y1 && pz > z0 && pz < z1;     // NaN fails every test, like numpy
+    }
+    const unsigned long long bal = __ballot(keep);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) {
+      if (w < wave) woff += wsum[w];
+      tot += wsum[w];
+    }
+    if (keep) {
+      float* dst = work + (size_t)(carry + woff + before) * C;
+      for (int c = 0; c < C; ++c) dst[c] = pts[(size_t)i * C + c];
+    }
+    __syncthreads();
+    if (tid == 0) carry += tot;
+    __syncthreads();
+  }
+  const int total = carry;
+  if (tid == 0) *count = total;
+  __threadfence_block();
+  __syncthreads();
+  const bool gather = choice != nullptr && total >= max_points;
+  for (long long e = tid; e < (long long)max_points * C; e += 1024) {
+    const int r = (int)(e / C), c = (int)(e - (long long)r * C);
+    float v = 0.f;
+    if (gather) {
+      const long long s = choice[r];
+      if (s >= 0 && s < total) v = work[(size_t)s * C + c];
+    } else if (r < total) {
+      v = work[(size_t)r * C + c];
+    }
+    out[e] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int bevf_resize_normalize_u8(const unsigned char* x, float* out, int n, int H, int W, int Ho, int Wo,
+                                        const int32_t* bounds_h, const int32_t* coef_h, int ksize_h,
+                                        const int32_t* bounds_v, const int32_t* coef_v, int ksize_v, const float* mean3,
+                                        const float* std3, void* stream) {
+  BEVF_REQUIRE(x && out && bounds_h && coef_h && bounds_v && coef_v && mean3 && std3, "resize_normalize: null pointer");
+  BEVF_REQUIRE(n > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && ksize_h > 0 && ksize_v > 0, "resize_normalize: bad shape");
+  BEVF_REQUIRE(std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, "resize_normalize: zero std");
+  const long long total = (long long)n * Ho * Wo;
+  BEVF_REQUIRE((total + 255) / 256 < (1ll << 31), "resize_normalize: grid too large");
+  hipLaunchKernelGGL(resize_normalize_u8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, out, n, H, W, Ho, Wo, bounds_h, coef_h, ksize_h, bounds_v,
+                     coef_v, ksize_v, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+  return bevf_check_launch("bevf_resize_normalize_u8");
+}
+
+extern "C" int bevf_lidar_filter_pad_f32(const float* points, float* out, int32_t* count, float* work,
+                                         const int64_t* choice, int N, int C, int max_points, const float* pc_range6,
+                                         void* stream) {
+  BEVF_REQUIRE((points || N == 0) && out && count && work && pc_range6, "lidar_filter_pad: null pointer");
+  BEVF_REQUIRE(N >= 0 && C >= 3 && max_points > 0, "lidar_filter_pad: need N >= 0, C >= 3, max_points > 0");
+  hipLaunchKernelGGL(lidar_filter_pad, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), points, out, count, work,
+                     reinterpret_cast<const long long*>(choice), N, C, max_points, pc_range6[0], pc_range6[1], pc_range6[2],
+                     pc_range6[3], pc_range6[4], pc_range6[5]);
+  return bevf_check_launch("bevf_lidar_filter_pad_f32");
+}

@@ -344,6 +344,25 @@ int bevf_grad_norm_f32(const float* g, size_t n, double* work512, float max_norm
 int bevf_adamw_step_f32(float* p, const float* g, float* m, float* v, const float* clip2, size_t n, float lr,
                         float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
 
+/* ==========================================================================================
+ * Input pipeline (ref src/train_detect.py:123-189, the dataset's per-sample host work)
+ * ========================================================================================== */
+
+/* uint8 HWC frames -> Pillow-identical antialiased bilinear resize (T.Resize on a PIL image: 22-bit fixed point,
+ * uint8 after the horizontal pass) -> /255 -> (t-mean)/std -> planar fp32 [n][3][Ho][Wo].  bounds_* [out][2] =
+ * (first source index, count), coef_* [out][ksize] = Pillow's integer weights for that axis (host:
+ * preprocess.resample_tables).  Replaces ref src/train_detect.py:127-143.                                        */
+int bevf_resize_normalize_u8(const unsigned char* x, float* out, int n, int H, int W, int Ho, int Wo,
+                             const int32_t* bounds_h, const int32_t* coef_h, int ksize_h, const int32_t* bounds_v,
+                             const int32_t* coef_v, int ksize_v, const float* mean3, const float* std3, void* stream);
+
+/* One LiDAR sweep [N][C]: keep points strictly inside pc_range6 = (x0,y0,z0,x1,y1,z1), in input order; out
+ * [max_points][C] = the survivors then zero rows, or survivors[choice[i]] when `choice` (max_points int64 indices,
+ * the reference's np.random.choice) is given and at least max_points survive.  count = number of survivors.
+ * work: N*C floats.  Replaces ref src/train_detect.py:150-159, 181-189.                                          */
+int bevf_lidar_filter_pad_f32(const float* points, float* out, int32_t* count, float* work, const int64_t* choice,
+                              int N, int C, int max_points, const float* pc_range6, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
