@@ -785,10 +785,12 @@ class FusedAdamW(torch.optim.Optimizer):
         self.last_grad_norm: Optional[torch.Tensor] = None
         self._arenas = None
 
-    def _build(self):
+    def _build(self, chosen=None):
+        """Arena per group over the parameters that receive gradients (or `chosen`: per-group lists, when a saved
+        state is loaded before the first step)."""
         self._arenas = []
-        for group in self.param_groups:
-            ps = [p for p in group["params"] if p.grad is not None]
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group["params"] if p.grad is not None] if chosen is None else chosen[gi]
             if not ps:
                 self._arenas.append(None)
                 continue
@@ -833,3 +835,61 @@ class FusedAdamW(torch.optim.Optimizer):
                                            _st()), "bevf_adamw_step_f32")
             for p in with_grad:                      # the kernel wrote through raw pointers: tell torch (and the
                 torch.autograd.graph.increment_version(p)   # engines' repack signature) that the values changed
+
+    # ---- torch.optim.AdamW's state layout, both ways (checkpoint compatibility) ---------------------------
+    def state_dict(self):
+        """Same structure as torch.optim.AdamW.state_dict(): per-parameter `step` / `exp_avg` / `exp_avg_sq`, indexed by
+        the parameter's position; the file loads into either optimiser."""
+        index, groups, k = {}, [], 0
+        for group in self.param_groups:
+            ids = []
+            for p in group["params"]:
+                index[id(p)] = k
+                ids.append(k)
+                k += 1
+            g = {key: val for key, val in group.items() if key != "params"}
+            g.update(amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                     decoupled_weight_decay=True)
+            g["params"] = ids
+            groups.append(g)
+        state = {}
+        for ar in self._arenas or []:
+            if ar is None:
+                continue
+            off = 0
+            for p in ar["params"]:
+                n = p.numel()
+                state[index[id(p)]] = {"step": torch.tensor(float(ar["step"])),
+                                       "exp_avg": ar["m"][off:off + n].view(p.shape).clone(),
+                                       "exp_avg_sq": ar["v"][off:off + n].view(p.shape).clone()}
+                off += n
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, state_dict):
+        groups = state_dict["param_groups"]
+        if len(groups) != len(self.param_groups) or any(len(a["params"]) != len(b["params"])
+                                                       for a, b in zip(groups, self.param_groups)):
+            raise ValueError("loaded state dict does not match the optimiser's parameter groups")
+        chosen, entries = [], []
+        for saved, group in zip(groups, self.param_groups):
+            for key in ("lr", "betas", "eps", "weight_decay"):
+                if key in saved:
+                    group[key] = tuple(saved[key]) if key == "betas" else saved[key]
+            have = [(p, state_dict["state"][i]) for i, p in zip(saved["params"], group["params"]) if i in state_dict["state"]]
+            chosen.append([p for p, _ in have])
+            entries.append([e for _, e in have])
+        with torch.no_grad():
+            self._build(chosen)
+            for ar, ent in zip(self._arenas, entries):
+                if ar is None:
+                    continue
+                off, steps = 0, set()
+                for p, e in zip(ar["params"], ent):
+                    n = p.numel()
+                    ar["m"][off:off + n].copy_(e["exp_avg"].reshape(-1))
+                    ar["v"][off:off + n].copy_(e["exp_avg_sq"].reshape(-1))
+                    steps.add(int(float(e["step"])))
+                    off += n
+                if len(steps) > 1:
+                    raise ValueError(f"FusedAdamW keeps one step count per group; the loaded state has {sorted(steps)}")
+                ar["step"] = steps.pop() if steps else 0

@@ -139,3 +139,43 @@ TRAIN_TRACKED = (
     "fusion.lidar_upsample.4.weight", "fusion.bev_fusion.0.weight", "fusion.bev_fusion.4.bias",
     "det_head.heatmap_head.2.bias", "det_head.size_head.0.weight", "det_head.vel_head.2.weight",
 )
+
+
+# ---- evaluation metrics (ref src/utils_v2.py:94-205) ------------------------------------------------------------------
+METRICS_CASES = [
+    dict(name="dense", frames=6, gts=30, preds=60, jitter=0.8, seed=601, tensors=False),
+    dict(name="sparse_far", frames=4, gts=8, preds=40, jitter=3.0, seed=602, tensors=False),
+    dict(name="torch_inputs", frames=3, gts=20, preds=25, jitter=0.5, seed=603, tensors=True),
+    dict(name="with_empty_frames", frames=5, gts=12, preds=12, jitter=1.0, seed=604, tensors=False, empty=True),
+]
+
+
+def metrics_inputs(c):
+    """Predictions = jittered ground truth + clutter, with padded (-1) labels and tied scores in the mix."""
+    preds, gts = [], []
+    for f in range(c["frames"]):
+        s = c["seed"] * 1009 + f * 17
+        ng, npred = c["gts"], c["preds"]
+        if c.get("empty") and f == 1:
+            ng = 0
+        if c.get("empty") and f == 2:
+            npred = 0
+        gb = torch.cat([synth.uniform((ng, 2), s + 1, -50.0, 50.0), synth.uniform((ng, 1), s + 2, -2.0, 1.0),
+                        synth.uniform((ng, 3), s + 3, 0.5, 5.0), synth.uniform((ng, 1), s + 4, -3.14, 3.14)], 1)
+        gl = synth.randint((ng,), s + 5, 0, 4).to(torch.int64)
+        if ng > 3:
+            gl[-1] = -1                                        # padding label
+        k = min(ng, npred)
+        pb = torch.cat([gb[:k] + synth.normal((k, 7), s + 6, 0.0, c["jitter"]) * torch.tensor([1, 1, .2, .3, .3, .3, .4]),
+                        torch.cat([synth.uniform((npred - k, 2), s + 7, -50.0, 50.0), synth.uniform((npred - k, 5), s + 8, 0.5, 3.0)], 1)], 0)
+        pl = torch.cat([gl[:k].clamp(min=0), synth.randint((npred - k,), s + 9, 0, 4).to(torch.int64)], 0)
+        ps = synth.uniform((npred,), s + 10, 0.05, 1.0)
+        if npred > 4:
+            ps[3] = ps[1]                                      # a tie
+        if c["tensors"]:
+            preds.append(dict(boxes=pb, scores=ps, labels=pl))
+            gts.append(dict(boxes=gb, labels=gl))
+        else:
+            preds.append(dict(boxes=pb.numpy(), scores=ps.numpy(), labels=pl.numpy()))
+            gts.append(dict(boxes=gb.numpy(), labels=gl.numpy()))
+    return preds, gts
