@@ -201,8 +201,32 @@ __global__ __launch_bounds__(256) void zero_stuff(const float* __restrict__ dy, 
   }
 }
 
+// ---- data gradient of a stride-2 conv, assembled from its four parity classes ------------------------------------------
+// dx[n][ih][iw][:] = cls[(ih&1)*2 + (iw&1)][n][ih>>1][iw>>1][:]  (class q stored with spatial size hq x wq; null = zeros)
+struct Interleave4 {
+  const float* cls[4];
+  int hq[4], wq[4];
+};
+__global__ __launch_bounds__(256) void interleave2x2(const Interleave4 a, float* __restrict__ dx, int N, int H, int W, int C) {
+  const int c4 = C >> 2;
+  const long long total = (long long)N * H * W * c4;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % c4) * 4;
+    long long pix = i / c4;
+    const int iw = (int)(pix % W);
+    pix /= W;
+    const int ih = (int)(pix % H), n = (int)(pix / H);
+    const int q = (ih & 1) * 2 + (iw & 1);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (a.cls[q]) v = *reinterpret_cast<const f32x4*>(a.cls[q] + ((size_t)(n * a.hq[q] + (ih >> 1)) * a.wq[q] + (iw >> 1)) * C + c);
+    *reinterpret_cast<f32x4*>(dx + (size_t)i * 4) = v;
+  }
+}
+
 // ---- dense layer backward ------------------------------------------------------------------------------------------
 // dx[b][k] = sum_o dy[b][perm(o)] * W[o][k]: workgroup = chunk of outputs, partial sums -> part[g][b][k]
+// Streams W once with 16-byte loads: thread (kq, osub) owns k = 4kq..4kq+3 and every `lanes`-th row of the workgroup's
+// chunk, 4 rows in flight; each (workgroup, osub) pair writes its own partial slot, merged in fixed order afterwards.
 __global__ __launch_bounds__(256) void linear_bwd_dx_partials(const float* __restrict__ dy, const float* __restrict__ w,
                                                                float* __restrict__ part, int B, int K, int O, int chunk,
                                                                int perm_inner, int perm_outer) {
@@ -214,22 +238,38 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_partials(const float* __res
     sdy[i] = dy[(size_t)b * O + oo];
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < K; k += 256) {
-    float acc[8];
+  const int k4 = K >> 2, per = k4 < 256 ? k4 : 256, lanes = 256 / per;
+  const int osub = threadIdx.x / per;
+  if (osub >= lanes) return;
+  for (int kq = threadIdx.x % per; kq < k4; kq += per) {
     for (int b0 = 0; b0 < B; b0 += 8) {
       const int nb = B - b0 < 8 ? B - b0 : 8;
+      f32x4 acc[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-      for (int o = o0; o < o1; ++o) {
-        const float wv = w[(size_t)o * K + k];
+      for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      int o = o0 + osub;
+      for (; o + 3 * lanes < o1; o += 4 * lanes) {
+        f32x4 wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wv[u] = *reinterpret_cast<const f32x4*>(w + (size_t)(o + u * lanes) * K + kq * 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float* g = sdy + (o + u * lanes - o0) * B + b0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (j < nb) acc[j] += g[j] * wv[u];
+        }
+      }
+      for (; o < o1; o += lanes) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (size_t)o * K + kq * 4);
         const float* g = sdy + (o - o0) * B + b0;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-          if (j < nb) acc[j] = fmaf(g[j], wv, acc[j]);
+          if (j < nb) acc[j] += g[j] * wv;
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        if (j < nb) part[((size_t)blockIdx.x * B + b0 + j) * K + k] = acc[j];
+        if (j < nb) *reinterpret_cast<f32x4*>(part + (((size_t)blockIdx.x * lanes + osub) * B + b0 + j) * K + kq * 4) = acc[j];
     }
   }
 }
@@ -522,17 +562,40 @@ extern "C" int bevf_zero_stuff_nhwc_f32(const float* dy, float* out, int N, int 
   hipLaunchKernelGGL(zero_stuff, dim3(ew_grid((long long)N * H * W * (C / 4))), dim3(256), 0, ST, dy, out, N, Ho, Wo, C, H, W, s);
   return bevf_check_launch("bevf_zero_stuff_nhwc_f32");
 }
-extern "C" size_t bevf_linear_bwd_work_floats(int B, int K, int O) { return (size_t)((O + 255) / 256 > 1024 ? 1024 : (O + 255) / 256) * B * K; }
+extern "C" int bevf_interleave2x2_nhwc_f32(const float* const* cls4, const int32_t* hq4, const int32_t* wq4, float* dx, int N,
+                                           int H, int W, int C, void* stream) {
+  BEVF_REQUIRE(cls4 && hq4 && wq4 && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "interleave2x2: bad arguments");
+  Interleave4 a;
+  for (int q = 0; q < 4; ++q) {
+    a.cls[q] = cls4[q]; a.hq[q] = hq4[q]; a.wq[q] = wq4[q];
+    const int need_h = (H - (q >> 1) + 1) / 2, need_w = (W - (q & 1) + 1) / 2;
+    BEVF_REQUIRE(!cls4[q] || (hq4[q] >= need_h && wq4[q] >= need_w), "interleave2x2: class %d is %dx%d, needs %dx%d", q, hq4[q],
+                 wq4[q], need_h, need_w);
+  }
+  hipLaunchKernelGGL(interleave2x2, dim3(ew_grid((long long)N * H * W * (C / 4))), dim3(256), 0, ST, a, dx, N, H, W, C);
+  return bevf_check_launch("bevf_interleave2x2_nhwc_f32");
+}
+static inline void linear_bwd_geometry(int K, int O, int* G, int* chunk, int* lanes) {
+  const int k4 = K >> 2, per = k4 < 256 ? k4 : 256;
+  *lanes = 256 / per;
+  int g = (O + 127) / 128;
+  if (g > 1024) g = 1024;
+  *chunk = (O + g - 1) / g;
+  *G = (O + *chunk - 1) / *chunk;
+}
+extern "C" size_t bevf_linear_bwd_work_floats(int B, int K, int O) {
+  int G, chunk, lanes;
+  linear_bwd_geometry(K, O, &G, &chunk, &lanes);
+  return (size_t)G * lanes * B * K;
+}
 extern "C" int bevf_linear_bwd_f32(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db,
                                    float* work, int B, int K, int O, int perm_inner, int perm_outer, void* stream) {
   BEVF_REQUIRE(dy && x && w && dw && work && B > 0 && B <= 64 && K > 0 && K % 4 == 0 && O > 0, "linear_bwd: bad arguments (B <= 64)");
-  int G = (O + 255) / 256;
-  if (G > 1024) G = 1024;
-  const int chunk = (O + G - 1) / G;
-  G = (O + chunk - 1) / chunk;
+  int G, chunk, lanes;
+  linear_bwd_geometry(K, O, &G, &chunk, &lanes);
   if (dx) {
     hipLaunchKernelGGL(linear_bwd_dx_partials, dim3(G), dim3(256), (size_t)chunk * B * sizeof(float), ST, dy, w, work, B, K, O, chunk, perm_inner, perm_outer);
-    hipLaunchKernelGGL(linear_bwd_dx_final, dim3((B * K + 255) / 256), dim3(256), 0, ST, work, dx, B * K, G);
+    hipLaunchKernelGGL(linear_bwd_dx_final, dim3((B * K + 255) / 256), dim3(256), 0, ST, work, dx, B * K, G * lanes);
   }
   hipLaunchKernelGGL(linear_bwd_dw, dim3(ew_grid((long long)O * (K / 4))), dim3(256), 0, ST, dy, x, dw, db, B, K, O, perm_inner, perm_outer);
   return bevf_check_launch("bevf_linear_bwd_f32");

@@ -77,10 +77,46 @@ def conv_wgrad(x, dy, N, H, W, cin, cout, k, stride, pad, dw=None) -> torch.Tens
     return dw[:cout * k * k * cin].view(cout, k, k, cin)
 
 
+def _dgrad_conv(src, filt_oihw_sub, N, Hs, Ws, cin, cout, kh, kw):
+    """One stride-1, pad-0 correlation of `src` [N][Hs][Ws][cout] with taps filt[t][u] -> [N][Hs-kh+1][Ws-kw+1][cin]."""
+    wt = filt_oihw_sub.permute(1, 2, 3, 0).contiguous().view(-1)                         # [cin][kh][kw][cout]
+    ho, wo = Hs - kh + 1, Ws - kw + 1
+    out = _new(N * ho * wo * cin, src.device)
+    L.conv2d_nhwc(src, wt, None, None, out, N=N, H=Hs, W=Ws, Cin=cout, x_cs=cout, Cout=cin, y_cs=cin, KH=kh, KW=kw,
+                  stride=1, pad=0, relu=False)
+    return out, ho, wo
+
+
 def conv_dgrad(dy, weight_oihw, N, H, W, cin, cout, k, stride, pad):
-    """dX [N*H*W*cin] = conv_transpose(dy, W): the forward kernel on (zero-stuffed) dy with the flipped filter."""
+    """dX [N*H*W*cin] = conv_transpose(dy, W).  Stride 1: the forward kernel on dy with the flipped filter.  Stride 2
+    (3x3 pad 1, or 1x1 pad 0 -- the ResNet shapes): the four input-parity classes (ih&1, iw&1) each see a fixed subset
+    of the taps, so each is a small stride-1 conv over dy (1x1 / 1x2 / 2x1 / 2x2 taps) and `interleave2x2` assembles dX:
+    exactly the forward's MFMA work instead of 4x on a zero-stuffed grid.  Other strides: zero stuffing."""
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    wt = weight_oihw.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous().view(-1)        # [cin][k][k][cout]
+    flops = 2.0 * N * Ho * Wo * cout * k * k * cin                                       # algorithmic
+    w = weight_oihw.detach()
+    if stride == 2 and (k, pad) in ((3, 1), (1, 0)):
+        dx = _new(N * H * W * cin, dy.device)
+        with E._span("conv_dgrad_f32", flops=flops):
+            if k == 1:
+                c00, h0, w0 = _dgrad_conv(dy, w, N, Ho, Wo, cin, cout, 1, 1)
+                cls, hq, wq = [c00, None, None, None], [h0, 0, 0, 0], [w0, 0, 0, 0]
+            else:
+                src = _new(N * (Ho + 1) * (Wo + 1) * cout, dy.device)                      # dy with a zero row / column appended
+                _ck(_lib().bevf_zero_stuff_nhwc_f32(dy.data_ptr(), src.data_ptr(), N, Ho, Wo, cout, Ho + 1, Wo + 1, 1, _st()),
+                    "bevf_zero_stuff_nhwc_f32")
+                taps = ([1], [2, 0])                                                       # parity 0: kh=1 reads dy[a]; parity 1: kh=2 reads dy[a], kh=0 reads dy[a+1]
+                cls, hq, wq = [], [], []
+                for ph in (0, 1):
+                    for pw in (0, 1):
+                        sub = w[:, :, taps[ph]][:, :, :, taps[pw]]
+                        c, hc, wc = _dgrad_conv(src, sub, N, Ho + 1, Wo + 1, cin, cout, len(taps[ph]), len(taps[pw]))
+                        cls.append(c); hq.append(hc); wq.append(wc)
+            ptrs = (C.c_void_p * 4)(*[None if c is None else c.data_ptr() for c in cls])
+            _ck(_lib().bevf_interleave2x2_nhwc_f32(ptrs, (C.c_int32 * 4)(*hq), (C.c_int32 * 4)(*wq), dx.data_ptr(), N, H, W, cin,
+                                                   _st()), "bevf_interleave2x2_nhwc_f32")
+        return dx
+    wt = w.flip(2, 3).permute(1, 2, 3, 0).contiguous().view(-1)                          # [cin][k][k][cout]
     src, sh, sw = dy, Ho, Wo
     if stride != 1:
         src = _new(N * H * W * cout, dy.device)
@@ -90,7 +126,7 @@ def conv_dgrad(dy, weight_oihw, N, H, W, cin, cout, k, stride, pad):
     else:
         assert (Ho, Wo) == (H, W), "stride-1 convs on this path keep the spatial size"
     dx = _new(N * H * W * cin, dy.device)
-    with E._span("conv_dgrad_f32", flops=2.0 * N * Ho * Wo * cout * k * k * cin):     # algorithmic (no zero-stuffing waste)
+    with E._span("conv_dgrad_f32", flops=flops):
         L.conv2d_nhwc(src, wt, None, None, dx, N=N, H=sh, W=sw, Cin=cout, x_cs=cout, Cout=cin, y_cs=cin, KH=k, KW=k,
                       stride=1, pad=k - 1 - pad, relu=False)
     return dx

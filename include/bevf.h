@@ -297,6 +297,11 @@ int bevf_conv2d_wgrad_f32(const bevf_wgrad_desc* d, void* stream);
 /* Data gradient: the forward kernel (bevf_conv2d_nhwc_f32) run on dy with the spatially flipped, channel-
  * transposed filter; strided convs first spread dy onto the input grid with zeros in between:            */
 int bevf_zero_stuff_nhwc_f32(const float* dy, float* out, int N, int Ho, int Wo, int C, int H, int W, int s, void* stream);
+/* Stride-2 data gradients without the zeros: the four input-parity classes are each a small stride-1 conv over dy
+ * (1x1, 1x2, 2x1, 2x2 taps for a 3x3 filter); this writes dx[n][ih][iw] = cls[(ih&1)*2+(iw&1)][n][ih>>1][iw>>1]
+ * (class q stored hq[q] x wq[q]; a null class is zeros, e.g. three of the four for a 1x1 stride-2 conv).          */
+int bevf_interleave2x2_nhwc_f32(const float* const* cls4, const int32_t* hq4, const int32_t* wq4, float* dx, int N, int H,
+                                int W, int C, void* stream);
 
 /* Train-mode BatchNorm{1,2}d over rows [M][C] (channel stride cs): batch mean / biased variance / invstd
  * (two-stage, fixed order, shifted sums), apply (+residual)(+ReLU), and backward:

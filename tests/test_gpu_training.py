@@ -21,7 +21,9 @@ def nhwc(x):
 
 @pytest.mark.parametrize("N,H,W,cin,cout,k,stride,pad", [(2, 9, 13, 32, 64, 3, 1, 1), (1, 17, 11, 64, 128, 3, 2, 1),
                                                           (2, 8, 8, 64, 128, 1, 2, 0), (1, 40, 36, 128, 256, 3, 1, 1),
-                                                          (700, 1, 1, 64, 128, 1, 1, 0), (3, 6, 5, 256, 320, 3, 1, 1)])
+                                                          (700, 1, 1, 64, 128, 1, 1, 0), (3, 6, 5, 256, 320, 3, 1, 1),
+                                                          (2, 16, 12, 64, 128, 3, 2, 1), (1, 13, 10, 128, 256, 3, 2, 1),
+                                                          (2, 9, 7, 128, 256, 1, 2, 0), (1, 2, 2, 64, 64, 3, 2, 1)])
 def test_conv_wgrad_dgrad(gpu, N, H, W, cin, cout, k, stride, pad):
     x = synth.normal((N, cin, H, W), 1).requires_grad_(True)
     w = synth.normal((cout, cin, k, k), 2, 0, 0.05).requires_grad_(True)
