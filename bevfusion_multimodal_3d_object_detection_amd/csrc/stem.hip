@@ -43,36 +43,10 @@ __host__ __device__ constexpr StemStep stem_step(int p) {
   return {((2 * PR + 6) * PW + 6 + 1) * 4, 146 * 256, 3};                      // (2,6,6) | zero row 147
 }
 
-template <typename TO>
-__global__ __launch_bounds__(256) void stem_conv7x7(const float* __restrict__ x, const float* __restrict__ w,
-                                                     const float* __restrict__ scale,
-                                                     const float* __restrict__ shift, TO* __restrict__ y,
-                                                         int H, int W, int Ho, int Wo, int tilesW, int tilesH,
-                                                         int vec_ok, int relu) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* wl = smem;                      // [KPAD][64]
-  float* patch = smem + KPAD * 64;       // [3][PR][PW]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tw = blockIdx.x % tilesW;
-  const int th = (blockIdx.x / tilesW) % tilesH;
-  const int n = blockIdx.x / (tilesW * tilesH);
-  const int ow0 = tw * TP, oh0 = th * TH;
-
-  // Staging is written for a minimal VALU count (every vector-ALU instruction here queues behind the other
-  // workgroup's 64-cycle MFMAs): per-lane offsets are computed once, rows advance on the scalar unit.
-  // filter bank, pre-packed by the host as [k = c*49+kh*7+kw][co] with a zero row k = 147
-  {
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, KPAD * 64 * 4, 0x00020000);
-    const unsigned voff = (unsigned)tid * 16u;
-#pragma unroll
-    for (int it = 0; it < (KPAD * 16 + 255) / 256; ++it) {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, voff, it * 4096, 0);
-      if (it * 256 + 255 < KPAD * 16 || tid < KPAD * 16 - it * 256)
-        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(wl) + tid * 16 + it * 4096) = v;
-    }
-  }
-  // patch row (c, pr) <-> image row ih = 2*oh0 - 3 + pr of plane c; patch col <-> iw = 2*ow0 - 4 + col
+// Stage the 3 x PR input rows a tile of TH output rows x TP pixels needs into LDS, zero-filled outside the image.
+// patch row (c, pr) <-> image row ih = 2*oh0 - 3 + pr of plane c; patch col <-> iw = 2*ow0 - 4 + col
+__device__ __forceinline__ void stage_patch(const float* __restrict__ x, float* patch, int n, int H, int W, int oh0, int ow0,
+                                            int vec_ok, int tid, int lane, int wave) {
   const float* img = x + (size_t)n * 3 * H * W;
   const int iw0 = 2 * ow0 - 4;
   if (vec_ok) {                          // W % 4 == 0 and 16-B aligned rows: whole float4s are in or out
@@ -105,6 +79,38 @@ __global__ __launch_bounds__(256) void stem_conv7x7(const float* __restrict__ x,
       patch[i] = ok ? img[((size_t)c * H + ih) * W + iw] : 0.f;
     }
   }
+}
+
+template <typename TO>
+__global__ __launch_bounds__(256) void stem_conv7x7(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, TO* __restrict__ y,
+                                                         int H, int W, int Ho, int Wo, int tilesW, int tilesH,
+                                                         int vec_ok, int relu) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* wl = smem;                      // [KPAD][64]
+  float* patch = smem + KPAD * 64;       // [3][PR][PW]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tw = blockIdx.x % tilesW;
+  const int th = (blockIdx.x / tilesW) % tilesH;
+  const int n = blockIdx.x / (tilesW * tilesH);
+  const int ow0 = tw * TP, oh0 = th * TH;
+
+  // Staging is written for a minimal VALU count (every vector-ALU instruction here queues behind the other
+  // workgroup's 64-cycle MFMAs): per-lane offsets are computed once, rows advance on the scalar unit.
+  // filter bank, pre-packed by the host as [k = c*49+kh*7+kw][co] with a zero row k = 147
+  {
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, KPAD * 64 * 4, 0x00020000);
+    const unsigned voff = (unsigned)tid * 16u;
+#pragma unroll
+    for (int it = 0; it < (KPAD * 16 + 255) / 256; ++it) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, voff, it * 4096, 0);
+      if (it * 256 + 255 < KPAD * 16 || tid < KPAD * 16 - it * 256)
+        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(wl) + tid * 16 + it * 4096) = v;
+    }
+  }
+  stage_patch(x, patch, n, H, W, oh0, ow0, vec_ok, tid, lane, wave);
   __syncthreads();
 
   const int h = lane >> 5, l31 = lane & 31;
@@ -182,6 +188,92 @@ __global__ __launch_bounds__(256) void stem_conv7x7(const float* __restrict__ x,
     if (relu) put(std::true_type{}); else put(std::false_type{});
   }
 }
+
+// ---- weight gradient of the stem: dW[co][k] = sum over pixels dY[pixel][co] * patch(pixel, tap k) --------------------
+// Same tile (TH rows x TP pixels of one image, patch in LDS) as the forward.  Per output row the dY row tile
+// [128 pixels][64 channels] is staged next to the patch; MFMA tiles C[i = channel][j = tap] (2 x 5 tiles of 32x32, 160
+// accumulator registers per wave), the reduction dimension is the pixel: A = dY (lane = channel), B = the patch value
+// under the lane's tap (per-lane tap base + immediate pixel offset).  Each wave owns 32 of the 128 pixels; a
+// workgroup walks over many tiles (persistent) and adds its partial dW with float atomics once at the end, so the
+// image and dY are read once and no im2col matrix is ever written.  dw: [64][160] (k >= 147 unused), zero-filled.
+__global__ __launch_bounds__(256) void stem_wgrad(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
+                                                   int N, int H, int W, int Ho, int Wo, int tilesW, int tilesH, int vec_ok) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* patch = smem;                   // [3][PR][PW]
+  float* dyt = smem + 3 * PR * PW;       // [TP][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  // lane's tap of tile t: k = 32 t + l31 (clamped: the pad taps repeat tap 146, their columns are never read back)
+  unsigned tapoff[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    int k = 32 * t + l31;
+    k = k < 147 ? k : 146;
+    const int c = k / 49, r = k - c * 49, kh = r / 7, kw = r - kh * 7;
+    tapoff[t] = (unsigned)((((c * PR + kh) * PW + kw + 1) + 2 * (wv * 32 + h)) * 4);
+  }
+  const unsigned aoff = (unsigned)(((wv * 32 + h) * 64 + l31) * 4);
+  f32x16 acc[2][5];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+
+  const int ntiles = N * tilesH * tilesW;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tw = tile % tilesW, th = (tile / tilesW) % tilesH, n = tile / (tilesW * tilesH);
+    const int ow0 = tw * TP, oh0 = th * TH;
+    __syncthreads();                                  // previous tile fully consumed
+    stage_patch(x, patch, n, H, W, oh0, ow0, vec_ok, tid, lane, wave);
+    for (int ro = 0; ro < TH; ++ro) {
+      const int oh = oh0 + ro;
+      if (oh >= Ho) break;
+      if (ro) __syncthreads();                        // previous dY row consumed
+      {                                               // dY row tile: 128 pixels x 64 channels, zero past the row end
+        const int left = Wo - ow0;
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(dy) + ((size_t)(n * Ho + oh) * Wo + ow0) * 64, 0, (left > TP ? TP : left) * 256, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < TP * 64 * 4 / (256 * 16); ++it) {
+          // (whole offset in the vector operand: the scalar offset is not range-checked, and pixels past the row end must read 0)
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rd, (unsigned)(tid * 16 + it * 4096), 0, 0);
+          *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(dyt) + tid * 16 + it * 4096) = v;
+        }
+      }
+      __syncthreads();
+      const char* const pa = reinterpret_cast<const char*>(dyt) + aoff;
+      const char* const pb = reinterpret_cast<const char*>(patch) + 2 * ro * PW * 4;
+#pragma unroll 4
+      for (int st = 0; st < 16; ++st) {               // this wave's 32 pixels, two per MFMA
+        const float a0 = *reinterpret_cast<const float*>(pa + st * 512);
+        const float a1 = *reinterpret_cast<const float*>(pa + st * 512 + 128);
+        float b[5];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) b[t] = *reinterpret_cast<const float*>(pb + tapoff[t] + st * 16);
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+          acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[t], acc[0][t], 0, 0, 0);
+          acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[t], acc[1][t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // C[i][j]: i = channel within tile (rows from r and h), j = tap = 32 t + l31: 32 lanes write 128 contiguous bytes
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h, k = 32 * t + l31;
+        if (k < 147) atomicAdd(&dw[co * 160 + k], acc[i][t][r]);
+      }
+}
+
+constexpr size_t kStemWgradLds = (size_t)(3 * PR * PW + TP * 64) * sizeof(float);
 
 constexpr size_t kStemLds = (size_t)(KPAD * 64 + 3 * PR * PW) * sizeof(float);
 
@@ -272,4 +364,24 @@ extern "C" int bevf_maxpool3x3s2_nhwc_f32(const float* x, float* y, int N, int H
 }
 extern "C" int bevf_maxpool3x3s2_nhwc_bf16(const void* x, void* y, int N, int H, int W, int C, void* stream) {
   return maxpool_entry<__bf16>(x, y, N, H, W, C, stream);
+}
+
+// dW [64][160] += stem weight gradient (dw zero-filled by the caller; k = c*49+kh*7+kw, columns >= 147 stay zero)
+extern "C" int bevf_stem_wgrad_f32(const float* x, const float* dy, float* dw, int N, int H, int W, void* stream) {
+  BEVF_REQUIRE(x && dy && dw && N > 0 && H >= 1 && W >= 1, "stem_wgrad: bad arguments");
+  BEVF_REQUIRE(bevf_aligned16(dy), "stem_wgrad: dy must be 16-byte aligned");
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+  const int tilesW = (Wo + TP - 1) / TP, tilesH = (Ho + TH - 1) / TH;
+  const long long tiles = (long long)N * tilesH * tilesW;
+  BEVF_REQUIRE(tiles < (1ll << 31), "stem_wgrad: too many tiles");
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)kStemWgradLds);
+    attr_done = true;
+  }
+  const unsigned grid = (unsigned)(tiles < 512 ? tiles : 512);          // 2 workgroups per CU, each over many tiles
+  hipLaunchKernelGGL(stem_wgrad, dim3(grid), dim3(256), kStemWgradLds, static_cast<hipStream_t>(stream), x, dy, dw, N, H, W, Ho,
+                     Wo, tilesW, tilesH, (W % 4 == 0 && bevf_aligned16(x)) ? 1 : 0);
+  return bevf_check_launch("bevf_stem_wgrad_f32");
 }

@@ -273,13 +273,15 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_partials(const float* __res
     }
   }
 }
-__global__ __launch_bounds__(256) void linear_bwd_dx_final(const float* __restrict__ part, float* __restrict__ dx, int BK,
+// out[slice][i] = sum of part[g][i] over the slice's range of g (fixed order, double); slices = gridDim.y
+__global__ __launch_bounds__(256) void linear_bwd_dx_final(const float* __restrict__ part, float* __restrict__ out, int BK,
                                                             int G) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= BK) return;
+  const int per = (G + gridDim.y - 1) / gridDim.y, g0 = blockIdx.y * per, g1 = g0 + per < G ? g0 + per : G;
   double s = 0;
-  for (int g = 0; g < G; ++g) s += part[(size_t)g * BK + i];
-  dx[i] = (float)s;
+  for (int g = g0; g < g1; ++g) s += part[(size_t)g * BK + i];
+  out[(size_t)blockIdx.y * BK + i] = (float)s;
 }
 // dW[o][k] = sum_b dy[b][perm(o)] * x[b][k];  db[o] = sum_b dy[b][perm(o)]
 __global__ __launch_bounds__(256) void linear_bwd_dw(const float* __restrict__ dy, const float* __restrict__ x,
@@ -575,18 +577,20 @@ extern "C" int bevf_interleave2x2_nhwc_f32(const float* const* cls4, const int32
   hipLaunchKernelGGL(interleave2x2, dim3(ew_grid((long long)N * H * W * (C / 4))), dim3(256), 0, ST, a, dx, N, H, W, C);
   return bevf_check_launch("bevf_interleave2x2_nhwc_f32");
 }
+constexpr int kLinSlices = 32;
 static inline void linear_bwd_geometry(int K, int O, int* G, int* chunk, int* lanes) {
   const int k4 = K >> 2, per = k4 < 256 ? k4 : 256;
   *lanes = 256 / per;
-  int g = (O + 127) / 128;
-  if (g > 1024) g = 1024;
-  *chunk = (O + g - 1) / g;
-  *G = (O + *chunk - 1) / *chunk;
+  int c = (O + 1023) / 1024;                               // ~1000 workgroups stream W, at least 8 rows each
+  if (c < 8) c = 8;
+  if (c > 128) c = 128;
+  *chunk = c;
+  *G = (O + c - 1) / c;
 }
 extern "C" size_t bevf_linear_bwd_work_floats(int B, int K, int O) {
   int G, chunk, lanes;
   linear_bwd_geometry(K, O, &G, &chunk, &lanes);
-  return (size_t)G * lanes * B * K;
+  return (size_t)G * lanes * B * K + (size_t)kLinSlices * B * K;
 }
 extern "C" int bevf_linear_bwd_f32(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db,
                                    float* work, int B, int K, int O, int perm_inner, int perm_outer, void* stream) {
@@ -594,8 +598,11 @@ extern "C" int bevf_linear_bwd_f32(const float* dy, const float* x, const float*
   int G, chunk, lanes;
   linear_bwd_geometry(K, O, &G, &chunk, &lanes);
   if (dx) {
+    float* part2 = work + (size_t)G * lanes * B * K;
+    const unsigned gx = (unsigned)((B * K + 255) / 256);
     hipLaunchKernelGGL(linear_bwd_dx_partials, dim3(G), dim3(256), (size_t)chunk * B * sizeof(float), ST, dy, w, work, B, K, O, chunk, perm_inner, perm_outer);
-    hipLaunchKernelGGL(linear_bwd_dx_final, dim3((B * K + 255) / 256), dim3(256), 0, ST, work, dx, B * K, G * lanes);
+    hipLaunchKernelGGL(linear_bwd_dx_final, dim3(gx, kLinSlices), dim3(256), 0, ST, work, part2, B * K, G * lanes);
+    hipLaunchKernelGGL(linear_bwd_dx_final, dim3(gx, 1), dim3(256), 0, ST, part2, dx, B * K, kLinSlices);
   }
   hipLaunchKernelGGL(linear_bwd_dw, dim3(ew_grid((long long)O * (K / 4))), dim3(256), 0, ST, dy, x, dw, db, B, K, O, perm_inner, perm_outer);
   return bevf_check_launch("bevf_linear_bwd_f32");

@@ -396,19 +396,12 @@ class DetectorTape:
         draw, dgamma, dbeta = bn_train_backward(dpool_in, self.stem_bn, enc.bn1, relu=True)
         sink.add(enc.bn1.weight, dgamma)
         sink.add(enc.bn1.bias, dbeta)
-        # stem weight gradient: im2col (k = c*49+kh*7+kw, padded to 160) + the generic MFMA weight-gradient GEMM
+        # stem weight gradient: direct MFMA kernel on the image patches (no im2col matrix), dW as [64][160]
         Ni, H, W = self.cam_geom_in
-        M = N * H1 * W1
-        # (in image chunks: the column matrix must stay below the 2 GiB limit of 32-bit buffer offsets)
-        per_img = H1 * W1
-        chunk = max(1, min(Ni, (1 << 31) // (per_img * 160 * 4 + 1)))
         dwbuf = _zeros(64 * 160, d.device)
-        col = _new(chunk * per_img * 160, d.device)
-        for i0 in range(0, Ni, chunk):
-            n = min(chunk, Ni - i0)
-            _ck(_lib().bevf_stem_im2col_f32(self.imgs[i0:i0 + n].data_ptr(), col.data_ptr(), n, H, W, _st()),
-                "bevf_stem_im2col_f32")
-            conv_wgrad(col, draw[i0 * per_img * 64:], n * per_img, 1, 1, 160, 64, 1, 1, 0, dw=dwbuf)   # [64][160]
+        with E._span("conv_wgrad_f32", flops=2.0 * N * H1 * W1 * 64 * 147):
+            _ck(_lib().bevf_stem_wgrad_f32(self.imgs.data_ptr(), draw.data_ptr(), dwbuf.data_ptr(), Ni, H, W, _st()),
+                "bevf_stem_wgrad_f32")
         sink.add(enc.conv1.weight, dwbuf[:64 * 160].view(64, 160)[:, :147].reshape(64, 3, 7, 7))
 
     # -- PointNet ----------------------------------------------------------------------------------------------------------------

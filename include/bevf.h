@@ -342,6 +342,9 @@ int bevf_head_tail_bwd_f32(const bevf_head_bwd_desc* d, void* stream);
  * scratch2: 2 floats.                                                                                        */
 int bevf_centernet_loss_bwd_f32(const bevf_loss_desc* d, float* const dpred[5], float* scratch2, void* stream);
 int bevf_stem_im2col_f32(const float* x, float* col, int N, int H, int W, void* stream);   /* [M][160], k=c*49+kh*7+kw */
+/* Stem weight gradient without the column matrix: dw [64][160] (k = c*49+kh*7+kw, columns >= 147 unused, zero-filled
+ * by the caller) += sum over pixels dy[pixel][co] * x under tap k; x planar NCHW fp32, dy [N][Ho][Wo][64].       */
+int bevf_stem_wgrad_f32(const float* x, const float* dy, float* dw, int N, int H, int W, void* stream);
 int bevf_smallk_wgrad_f32(const float* dy, const float* x, float* dw, int M, int K, int Cout, void* stream);
 /* clip_grad_norm_: out2 = {total L2 norm, min(1, max_norm/(norm+1e-6))}; work512: 512 doubles.                */
 int bevf_grad_norm_f32(const float* g, size_t n, double* work512, float max_norm, float* out2, void* stream);

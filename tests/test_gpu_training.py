@@ -36,6 +36,25 @@ def test_conv_wgrad_dgrad(gpu, N, H, W, cin, cout, k, stride, pad):
     assert rel_err(dx[:N * H * W * cin].view(N, H, W, cin).permute(0, 3, 1, 2).cpu(), x.grad) <= 2e-5
 
 
+@pytest.mark.parametrize("N,H,W", [(2, 64, 96), (1, 37, 52), (3, 30, 33), (1, 448, 800)])
+def test_stem_weight_gradient_direct_kernel(gpu, N, H, W):
+    """bevf_stem_wgrad_f32 (no im2col) against autograd of the 7x7 stride-2 conv; W % 4 != 0 takes the scalar staging."""
+    import ctypes as C
+    x = synth.normal((N, 3, H, W), 5)
+    w = synth.normal((64, 3, 7, 7), 6, 0, 0.05).requires_grad_(True)
+    y = F.conv2d(x, w, None, 2, 3)
+    dy = synth.normal(tuple(y.shape), 7)
+    y.backward(dy)
+    dw = torch.zeros(64 * 160, device=gpu)
+    xg, dyg = x.cuda(), nhwc(dy)                                  # keep the device copies alive across the launch
+    rc = L.lib().bevf_stem_wgrad_f32(xg.data_ptr(), dyg.data_ptr(), dw.data_ptr(), N, H, W,
+                                     torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, L.lib().bevf_last_error()
+    got = dw.view(64, 160)[:, :147].reshape(64, 3, 7, 7).cpu()
+    assert rel_err(got, w.grad) <= 2e-5
+    assert not dw.view(64, 160)[:, 147:].any()
+
+
 @pytest.mark.parametrize("M,C,relu,res", [(1000, 64, True, True), (333, 256, True, False), (77, 1024, False, False), (5000, 128, True, False)])
 def test_bn_train_forward_backward(gpu, M, C, relu, res):
     bn = torch.nn.BatchNorm1d(C)
