@@ -308,6 +308,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dy
   }
 }
 
+// running statistics, as torch.nn.BatchNorm updates them in training mode (one launch instead of five tiny ones)
+__global__ __launch_bounds__(256) void bn_update_running(const float* __restrict__ mean, const float* __restrict__ var,
+                                                          float* __restrict__ rmean, float* __restrict__ rvar,
+                                                          long long* __restrict__ nbt, int C, float keep, float mom, float mom_unbiased) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c == 0 && nbt) *nbt += 1;
+  if (c >= C) return;
+  rmean[c] = fmaf(mom, mean[c], rmean[c] * keep);
+  rvar[c] = fmaf(mom_unbiased, var[c], rvar[c] * keep);
+}
+
 static inline unsigned row_grid(long long M, int C) {      // workgroups for the row-streaming kernels
   const int lanes = C / 4 >= 256 ? 1 : 256 / (C / 4);
   long long g = (M + (long long)lanes * 4 - 1) / ((long long)lanes * 4);
@@ -330,6 +341,16 @@ extern "C" int bevf_bn_stats_f32(const float* x, float* work, float* mean, float
   hipLaunchKernelGGL(stats_partials, dim3(G), dim3(256), 256 * 8 * sizeof(float), st, x, work, M, C, cs);
   hipLaunchKernelGGL(stats_finalize, dim3((C + 3) / 4), dim3(256), 0, st, x, work, mean, var, invstd, M, C, G, eps);
   return bevf_check_launch("bevf_bn_stats_f32");
+}
+
+extern "C" int bevf_bn_update_running_f32(const float* mean, const float* var, float* running_mean, float* running_var,
+                                          int64_t* num_batches_tracked, int C, int M, float momentum, void* stream) {
+  BEVF_REQUIRE(mean && var && running_mean && running_var && C > 0 && M > 0, "bn_update_running: bad arguments");
+  const float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.f;
+  hipLaunchKernelGGL(bn_update_running, dim3((C + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), mean, var,
+                     running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), C, 1.f - momentum, momentum,
+                     momentum * unbias);
+  return bevf_check_launch("bevf_bn_update_running_f32");
 }
 
 extern "C" int bevf_bn_apply_f32(const float* x, const float* mean, const float* invstd, const float* gamma,

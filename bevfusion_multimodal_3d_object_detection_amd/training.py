@@ -149,11 +149,14 @@ def bn_train_forward(xraw, bn: nn.BatchNorm2d, M: int, Cc: int, res=None, relu=T
                                  res.data_ptr() if res is not None else None, y.data_ptr(), M, Cc, Cc, int(relu), _st()),
         "bevf_bn_apply_f32")
     if bn.track_running_stats and bn.running_mean is not None:           # torch: momentum 0.1, unbiased running var
-        with torch.no_grad():
-            mom = 0.1 if bn.momentum is None else bn.momentum
-            bn.running_mean.mul_(1 - mom).add_(mean[:Cc], alpha=mom)
-            bn.running_var.mul_(1 - mom).add_(var[:Cc], alpha=mom * M / max(M - 1, 1))
-            bn.num_batches_tracked.add_(1)
+        mom = 0.1 if bn.momentum is None else bn.momentum
+        nbt = bn.num_batches_tracked
+        _ck(_lib().bevf_bn_update_running_f32(mean.data_ptr(), var.data_ptr(), bn.running_mean.data_ptr(),
+                                              bn.running_var.data_ptr(), nbt.data_ptr() if nbt is not None else None, Cc, M,
+                                              float(mom), _st()), "bevf_bn_update_running_f32")
+        for t in (bn.running_mean, bn.running_var, nbt):                 # written through raw pointers: bump the versions
+            if t is not None:                                             # (the engines' repack signature looks at them)
+                torch.autograd.graph.increment_version(t)
     s = _BNState()
     s.mean, s.invstd, s.xraw, s.y, s.M, s.C = mean, invstd, xraw, y, M, Cc
     return y, s

@@ -308,6 +308,10 @@ int bevf_interleave2x2_nhwc_f32(const float* const* cls4, const int32_t* hq4, co
  *   dy <- dy * (y > 0) if relu;  dbeta = sum dy;  dgamma = sum dy*xhat;
  *   dx = gamma*invstd*(dy - dbeta/M - xhat*dgamma/M)   (dx == NULL: only the sums -> conv bias gradients) */
 size_t bevf_bn_work_floats(int C);
+/* running_mean/var <- (1-momentum)*running + momentum*batch (variance unbiased by M/(M-1)), num_batches_tracked += 1
+ * (may be NULL): torch.nn.BatchNorm's training-mode buffer update in one launch.                                  */
+int bevf_bn_update_running_f32(const float* mean, const float* var, float* running_mean, float* running_var,
+                               int64_t* num_batches_tracked, int C, int M, float momentum, void* stream);
 int bevf_bn_stats_f32(const float* x, float* work, float* mean, float* var, float* invstd, int M, int C, int cs,
                       float eps, void* stream);
 int bevf_bn_apply_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
