@@ -158,10 +158,13 @@ __global__ __launch_bounds__(256) void bn_apply(const float* __restrict__ x, con
   }
 }
 
-// backward stage 1: dy <- dy * (y > 0) when relu; partial[g][c] = {sum dy, sum dy*xhat}
+// backward stage 1: dy <- dy * (y > 0) when relu; partial[g][c] = {sum dy, sum dy*xhat}.
+// relu == 2: the forward output is not read; the mask is recomputed from the raw input with the very operations of
+// bn_apply (t = fma(x, gamma*invstd, beta - mean*gamma*invstd) > 0) -- valid for layers without a residual input.
 __global__ __launch_bounds__(256) void bn_bwd_partials(float* __restrict__ dy, const float* __restrict__ y,
                                                         const float* __restrict__ x, const float* __restrict__ mean,
-                                                        const float* __restrict__ invstd, float* __restrict__ part,
+                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ part,
                                                         int M, int C, int cs, int relu) {
   extern __shared__ float red[];
   const int c4 = C >> 2;
@@ -170,9 +173,14 @@ __global__ __launch_bounds__(256) void bn_bwd_partials(float* __restrict__ dy, c
   for (int cq = threadIdx.x % (c4 < 256 ? c4 : 256); cq < c4; cq += 256) {
     const int rl = c4 >= 256 ? 0 : threadIdx.x / c4;
     if (rl >= lanes) break;
-    float mu[4], is[4];
+    float mu[4], is[4], fa[4], fb[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { mu[j] = mean ? mean[cq * 4 + j] : 0.f; is[j] = invstd ? invstd[cq * 4 + j] : 1.f; }
+    for (int j = 0; j < 4; ++j) {
+      mu[j] = mean ? mean[cq * 4 + j] : 0.f;
+      is[j] = invstd ? invstd[cq * 4 + j] : 1.f;
+      fa[j] = (gamma ? gamma[cq * 4 + j] : 1.f) * is[j];
+      fb[j] = (beta ? beta[cq * 4 + j] : 0.f) - mu[j] * fa[j];
+    }
     float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
     const long long step = (long long)gridDim.x * lanes;
     long long m = (long long)blockIdx.x * lanes + rl;
@@ -182,12 +190,16 @@ __global__ __launch_bounds__(256) void bn_bwd_partials(float* __restrict__ dy, c
       for (int u = 0; u < 4; ++u) {
         const size_t r = (size_t)(m + u * step);
         g[u] = *reinterpret_cast<const f32x4*>(dy + r * C + cq * 4);
-        if (relu) yy[u] = *reinterpret_cast<const f32x4*>(y + r * C + cq * 4);
+        if (relu == 1) yy[u] = *reinterpret_cast<const f32x4*>(y + r * C + cq * 4);
         if (x) xv[u] = *reinterpret_cast<const f32x4*>(x + r * cs + cq * 4);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (relu) {
+          if (relu == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) yy[u][j] = fmaf(xv[u][j], fa[j], fb[j]);
+          }
 #pragma unroll
           for (int j = 0; j < 4; ++j) g[u][j] = yy[u][j] > 0.f ? g[u][j] : 0.f;
           *reinterpret_cast<f32x4*>(dy + (size_t)(m + u * step) * C + cq * 4) = g[u];
@@ -202,7 +214,14 @@ __global__ __launch_bounds__(256) void bn_bwd_partials(float* __restrict__ dy, c
     for (; m < M; m += step) {
       f32x4 g = *reinterpret_cast<const f32x4*>(dy + (size_t)m * C + cq * 4);
       if (relu) {
-        const f32x4 yy = *reinterpret_cast<const f32x4*>(y + (size_t)m * C + cq * 4);
+        f32x4 yy;
+        if (relu == 1) {
+          yy = *reinterpret_cast<const f32x4*>(y + (size_t)m * C + cq * 4);
+        } else {
+          const f32x4 xr = *reinterpret_cast<const f32x4*>(x + (size_t)m * cs + cq * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) yy[j] = fmaf(xr[j], fa[j], fb[j]);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) g[j] = yy[j] > 0.f ? g[j] : 0.f;
         *reinterpret_cast<f32x4*>(dy + (size_t)m * C + cq * 4) = g;
@@ -365,18 +384,19 @@ extern "C" int bevf_bn_apply_f32(const float* x, const float* mean, const float*
 }
 
 extern "C" int bevf_bn_backward_f32(float* dy, const float* y, const float* x, const float* mean, const float* invstd,
-                                    const float* gamma, float* work, float* dgamma, float* dbeta, float* dx, int M,
-                                    int C, int cs, int relu, void* stream) {
+                                    const float* gamma, const float* beta, float* work, float* dgamma, float* dbeta,
+                                    float* dx, int M, int C, int cs, int relu, void* stream) {
   BEVF_REQUIRE(dy && work && dbeta, "bn_backward: null pointer");
-  BEVF_REQUIRE(!relu || y, "bn_backward: relu needs the forward output");
+  BEVF_REQUIRE(!relu || y || (x && mean && invstd), "bn_backward: relu needs the forward output, or x/mean/invstd to recompute it");
   BEVF_REQUIRE(!dx || (x && mean && invstd && dgamma), "bn_backward: dx needs x, mean, invstd, dgamma");
   BEVF_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && cs >= C && cs % 4 == 0, "bn_backward: bad shape");
+  const int relu_mode = relu ? (y ? 1 : 2) : 0;          // y == NULL: mask recomputed from x (no residual in the forward)
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int lanes = C / 4 >= 256 ? 1 : 256 / (C / 4);
   int G = (M + lanes - 1) / lanes;
   if (G > kStatGrid) G = kStatGrid;
-  hipLaunchKernelGGL(bn_bwd_partials, dim3(G), dim3(256), 256 * 8 * sizeof(float), st, dy, y, x, mean, invstd, work, M, C,
-                     cs, relu);
+  hipLaunchKernelGGL(bn_bwd_partials, dim3(G), dim3(256), 256 * 8 * sizeof(float), st, dy, y, x, mean, invstd, gamma, beta,
+                     work, M, C, cs, relu_mode);
   hipLaunchKernelGGL(sums_finalize, dim3((C + 3) / 4), dim3(256), 0, st, work, dbeta, dgamma, C, G);
   if (dx)
     hipLaunchKernelGGL(bn_bwd_apply, dim3(row_grid(M, C)), dim3(256), 0, st, dy, x, mean, invstd, gamma,

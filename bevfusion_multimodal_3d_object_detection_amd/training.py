@@ -133,7 +133,7 @@ def conv_dgrad(dy, weight_oihw, N, H, W, cin, cout, k, stride, pad):
 
 
 class _BNState:
-    __slots__ = ("mean", "invstd", "xraw", "y", "M", "C")
+    __slots__ = ("mean", "invstd", "xraw", "y", "M", "C", "has_res")
 
 
 def bn_train_forward(xraw, bn: nn.BatchNorm2d, M: int, Cc: int, res=None, relu=True):
@@ -158,7 +158,7 @@ def bn_train_forward(xraw, bn: nn.BatchNorm2d, M: int, Cc: int, res=None, relu=T
             if t is not None:                                             # (the engines' repack signature looks at them)
                 torch.autograd.graph.increment_version(t)
     s = _BNState()
-    s.mean, s.invstd, s.xraw, s.y, s.M, s.C = mean, invstd, xraw, y, M, Cc
+    s.mean, s.invstd, s.xraw, s.y, s.M, s.C, s.has_res = mean, invstd, xraw, y, M, Cc, res is not None
     return y, s
 
 
@@ -169,8 +169,11 @@ def bn_train_backward(dy, s: _BNState, bn, relu=True, need_dx=True):
     dgamma, dbeta = _new(s.C, dev), _new(s.C, dev)
     dx = _new(s.M * s.C, dev) if need_dx else None
     g = bn.weight.data_ptr() if bn.weight is not None else None
-    _ck(_lib().bevf_bn_backward_f32(dy.data_ptr(), s.y.data_ptr(), s.xraw.data_ptr(), s.mean.data_ptr(),
-                                    s.invstd.data_ptr(), g, work.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+    b = bn.bias.data_ptr() if bn.bias is not None else None
+    # without a residual the ReLU mask is recomputed from the raw input (same fma as the forward): y is not re-read
+    ymask = s.y.data_ptr() if (relu and s.has_res) else None
+    _ck(_lib().bevf_bn_backward_f32(dy.data_ptr(), ymask, s.xraw.data_ptr(), s.mean.data_ptr(),
+                                    s.invstd.data_ptr(), g, b, work.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                     dx.data_ptr() if dx is not None else None, s.M, s.C, s.C, int(relu), _st()),
         "bevf_bn_backward_f32")
     return dx, dgamma[:s.C], dbeta[:s.C]
@@ -180,7 +183,7 @@ def colsum(dy, M, Cc):
     """sum over rows (bias gradients)."""
     work = _new(_lib().bevf_bn_work_floats(Cc), dy.device)
     out = _new(Cc, dy.device)
-    _ck(_lib().bevf_bn_backward_f32(dy.data_ptr(), None, None, None, None, None, work.data_ptr(), None, out.data_ptr(),
+    _ck(_lib().bevf_bn_backward_f32(dy.data_ptr(), None, None, None, None, None, None, work.data_ptr(), None, out.data_ptr(),
                                     None, M, Cc, Cc, 0, _st()), "bevf_bn_backward_f32(colsum)")
     return out[:Cc]
 

@@ -316,9 +316,11 @@ int bevf_bn_stats_f32(const float* x, float* work, float* mean, float* var, floa
                       float eps, void* stream);
 int bevf_bn_apply_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                       const float* res, float* y, int M, int C, int cs, int relu, void* stream);
+/* relu with y == NULL: the mask is recomputed from x exactly as bn_apply computed it (gamma, beta as in the forward;
+ * only valid when the forward had no residual input) -- saves reading the forward output.                       */
 int bevf_bn_backward_f32(float* dy, const float* y, const float* x, const float* mean, const float* invstd,
-                         const float* gamma, float* work, float* dgamma, float* dbeta, float* dx, int M, int C,
-                         int cs, int relu, void* stream);
+                         const float* gamma, const float* beta, float* work, float* dgamma, float* dbeta, float* dx,
+                         int M, int C, int cs, int relu, void* stream);
 
 int bevf_add_inplace_f32(float* y, const float* x, size_t n, void* stream);            /* y += x            */
 int bevf_relu_mask_f32(float* dy, const float* y, size_t n, void* stream);             /* dy *= (y > 0)     */

@@ -1,3 +1,5 @@
+"""Per-step wall time (forward / backward / optimiser) and caching-allocator statistics of the training step at BASELINE
+config 4 -- the tool that exposed the per-step activation leak."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
