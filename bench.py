@@ -108,7 +108,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="frames per step per GPU (default 8; 2 for config 5, whose B=8 activations pass the 2 GiB buffer limit)")
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="train = BASELINE config 4: fwd + targets + loss + bwd + grad all-reduce + clip + AdamW")
@@ -132,9 +133,9 @@ def main():
     dist = replicas.init(backend, dev)             # RCCL; only for the barrier and the MAX of the elapsed time
     if args.mode == "train":
         args.config = 4
-        if args.batch == 4:
-            args.batch = 8                              # BASELINE config 4: per-GPU batch 8
     cfg = CONFIGS[args.config]
+    if args.batch is None:
+        args.batch = 2 if args.config == 5 else 8
 
     model_cpu = build_model(cfg)
     state = {k: v.clone() for k, v in model_cpu.state_dict().items()}

@@ -415,13 +415,13 @@ class FusionEngine(_Engine):
             pooled = cam
             if ncam > 1:
                 pooled = self.buf("cam_mean", B * Hc * Wc * Cc)
-                with _span("bev_pool", nbytes=4.0 * B * Hc * Wc * Cc * (ncam + 1)):
+                with _span("bev_pool", nbytes=float(cam.element_size()) * B * Hc * Wc * Cc * (ncam + 1)):
                     L.cam_mean(cam, pooled, B, ncam, Hc * Wc, Cc)
             t1 = self.buf("cam_t1", B * Hc * Wc * self.cam1.cout)
             _run_conv(self.cam1, pooled, t1, B, Hc, Wc)
             t2 = self.buf("cam_t2", B * Hc * Wc * self.cam2.cout)
             _run_conv(self.cam2, t1, t2, B, Hc, Wc)
-            with _span("bev_pool", nbytes=4.0 * B * bc * (Hc * Wc + Sh * Sw)):
+            with _span("bev_pool", nbytes=float(t2.element_size()) * B * bc * (Hc * Wc + Sh * Sw)):
                 L.bilinear_nhwc(t2, concat[slot * bc:], B, Hc, Wc, bc, bc, Sh, Sw, ccs)
             slot += 1
         if "l" in present:
