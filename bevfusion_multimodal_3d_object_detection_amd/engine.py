@@ -219,9 +219,29 @@ class CameraEncoderEngine(_Engine):
         self.proj = pack_conv(m.channel_proj[0], m.channel_proj[1], True)
 
     def run(self, x: torch.Tensor) -> Tuple[torch.Tensor, int, int]:
-        """x: (N,3,H,W) contiguous NCHW -> (NHWC buffer [N*Hc*Wc*Cout], Hc, Wc)."""
+        """x: (N,3,H,W) contiguous NCHW -> (NHWC buffer [N*Hc*Wc*Cout], Hc, Wc).
+        The conv kernels address their operands with 32-bit byte offsets (buffer instructions), so a trunk activation
+        must stay below 2 GiB: larger batches run the trunk in image chunks that write into one feature buffer."""
         self.ensure_packed()
         N, _, H, W = x.shape
+        H1, W1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        H2, W2 = (H1 - 1) // 2 + 1, (W1 - 1) // 2 + 1
+        es = 2 if self.dtype == torch.bfloat16 else 4
+        n_max = max(1, ((1 << 31) - 1) // (H2 * W2 * 64 * es))
+        h, w = H2, W2
+        for c1, _, _ in self.blocks:
+            h, w = (h + 2 - 3) // c1.stride + 1, (w + 2 - 3) // c1.stride + 1
+        feat = self.buf("feat", N * h * w * self.proj.cout)
+        if N <= n_max:
+            self._run_chunk(x, N, H, W, feat)
+        else:
+            per = -(-N // -(-N // n_max))                    # balanced chunks
+            for i0 in range(0, N, per):
+                n = min(per, N - i0)
+                self._run_chunk(x[i0:i0 + n], n, H, W, feat[i0 * h * w * self.proj.cout:])
+        return feat, h, w
+
+    def _run_chunk(self, x: torch.Tensor, N: int, H: int, W: int, feat: torch.Tensor) -> None:
         H1, W1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         H2, W2 = (H1 - 1) // 2 + 1, (W1 - 1) // 2 + 1
         stem = self.buf("stem", N * H1 * W1 * 64)
@@ -243,9 +263,7 @@ class CameraEncoderEngine(_Engine):
             out = self.buf(f"act{ping}", N * ho * wo * c2.cout)
             _run_conv(c2, t, out, N, ho, wo, res=idt)
             cur, h, w = out, ho, wo
-        feat = self.buf("feat", N * h * w * self.proj.cout)
         _run_conv(self.proj, cur, feat, N, h, w)
-        return feat, h, w
 
 
 # ---- shared per-point MLP + max (ref src/encoders.py:271-306) -------------------------------------------
@@ -264,8 +282,25 @@ class PointNetEngine(_Engine):
         self.layers = [pack_conv(c, b, True, split_ok=i < n - 1) for i, (c, b) in enumerate(zip(convs[1:], bns[1:]))]
 
     def run(self, pts: torch.Tensor, keep_last: bool = False):
-        """pts: (B,N,C) contiguous -> (B, feat) global max feature [and the (B*N, feat) last activations]."""
+        """pts: (B,N,C) contiguous -> (B, feat) global max feature [and the (B*N, feat) last activations].
+        Frames are processed in chunks when an activation of the whole batch would pass the kernels' 2 GiB limit."""
         self.ensure_packed()
+        B, N, Cc = pts.shape
+        es = 2 if self.dtype == torch.bfloat16 else 4
+        widest = max(pc.cout for pc in self.layers)
+        f_max = max(1, ((1 << 31) - 1) // (max(N, 1) * widest * es))
+        last = self.layers[-1]
+        gmax = torch.zeros(B, last.cout, dtype=torch.int32, device=pts.device)
+        if B <= f_max:
+            y = self._run_frames(pts, gmax, keep_last)
+            return gmax.view(torch.float32), y
+        if keep_last:
+            raise L.BevfError(f"PointNet: per-point features of {B}x{N} points exceed the 2 GiB activation limit")
+        for b0 in range(0, B, f_max):
+            self._run_frames(pts[b0:b0 + f_max], gmax[b0:b0 + f_max], False)
+        return gmax.view(torch.float32), None
+
+    def _run_frames(self, pts: torch.Tensor, gmax: torch.Tensor, keep_last: bool):
         B, N, Cc = pts.shape
         M = B * N
         a = self.buf("l0", M * self.c0)
@@ -275,10 +310,9 @@ class PointNetEngine(_Engine):
             _run_conv(pc, a, o, M, 1, 1)
             a = o
         last = self.layers[-1]
-        gmax = torch.zeros(B, last.cout, dtype=torch.int32, device=pts.device)
         y = self.buf("l_last", M * last.cout) if keep_last else None
         _run_conv(last, a, y, M, 1, 1, colmax=gmax, rows_per_group=N)
-        return gmax.view(torch.float32), y
+        return y
 
 
 class VFEEngine(_Engine):

@@ -78,3 +78,20 @@ def test_full_size_conv_linearity_and_tile_invariance(gpu):
     assert torch.equal(y4, outs[0] * 4.0)
     checksum = float(outs[0].double().sum())
     assert abs(checksum - float((outs[0].view(N, -1).double().sum(1)).sum())) <= 1e-6 * abs(checksum) + 1e-6
+
+
+def test_batches_beyond_the_2gib_activation_limit_run_in_chunks(gpu):
+    """16 frames of 6 x 900x1600: layer1's input (96 images) would be 2.2 GB, past the 32-bit buffer offsets of the
+    conv kernels, so the trunk runs in image chunks; frame k of the big batch must equal the same frame run alone."""
+    m = fusion.create_detector("camera+lidar", "bev", "centernet", bev_h=CFG["bev"], bev_w=CFG["bev"])
+    synth.fill_state_dict_(m, 0)
+    m = m.cuda().eval()
+    imgs, pts, _ = synth.frame_inputs(2, CFG["cams"], CFG["h"], CFG["w"], CFG["points"], 4, seed=77)
+    big_i = imgs.repeat(8, 1, 1, 1, 1).cuda()                    # frames 0,1,0,1,...: 16 frames
+    big_p = pts.repeat(8, 1, 1).cuda()
+    out = m(big_i, big_p, None)
+    assert out["heatmap"].shape[0] == 16
+    for k in (0, 1):
+        one = m(imgs[k:k + 1].cuda(), pts[k:k + 1].cuda(), None)
+        for name in one:
+            assert torch.equal(out[name][k:k + 1], one[name]) and torch.equal(out[name][14 + k:15 + k], one[name]), name
