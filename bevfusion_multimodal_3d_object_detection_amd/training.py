@@ -56,7 +56,28 @@ def _pixtab(N, H, W, k, stride, pad, x_cs, dev) -> torch.Tensor:
 
 # ---- primitive ops (thin wrappers over the C-ABI; all tensors fp32 cuda, flat NHWC) ---------------------------------
 
+# The conv kernels address their operands with 32-bit byte offsets: a tensor handed to one launch must stay below
+# BUF_LIMIT bytes.  Batches past that run as image chunks (outputs are slices of one buffer, weight gradients
+# accumulate); tests shrink BUF_LIMIT to exercise the chunking on small shapes.
+BUF_LIMIT = (1 << 31) - 1
+
+
+def _image_chunk(N: int, *per_image_elems: int) -> int:
+    n_max = max(1, BUF_LIMIT // (4 * max(per_image_elems)))
+    return N if N <= n_max else -(-N // -(-N // n_max))
+
+
 def conv_raw(x, w_ohwi, bias, N, H, W, cin, cout, k, stride, pad, relu=False):
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    per = _image_chunk(N, H * W * cin, Ho * Wo * cout)
+    if per < N:
+        y = _new(N * Ho * Wo * cout, x.device)
+        for i0 in range(0, N, per):
+            n = min(per, N - i0)
+            with E._span("conv_igemm_f32", flops=2.0 * n * Ho * Wo * cout * k * k * cin):
+                L.conv2d_nhwc(x[i0 * H * W * cin:], w_ohwi, None, bias, y[i0 * Ho * Wo * cout:], N=n, H=H, W=W, Cin=cin, x_cs=cin,
+                              Cout=cout, y_cs=cout, KH=k, KW=k, stride=stride, pad=pad, relu=relu)
+        return y, Ho, Wo
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     y = _new(N * Ho * Wo * cout, x.device)
     with E._span("conv_igemm_f32", flops=2.0 * N * Ho * Wo * cout * k * k * cin):
@@ -69,6 +90,13 @@ def conv_wgrad(x, dy, N, H, W, cin, cout, k, stride, pad, dw=None) -> torch.Tens
     """Returns dW in OHWI layout [cout][k][k][cin] (accumulates into `dw` when given)."""
     if dw is None:
         dw = _zeros(cout * k * k * cin, x.device)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    per = _image_chunk(N, H * W * cin, Ho * Wo * cout, Ho * Wo * k * k)          # (the tap table has the same limit)
+    if per < N:
+        for i0 in range(0, N, per):
+            n = min(per, N - i0)
+            conv_wgrad(x[i0 * H * W * cin:], dy[i0 * Ho * Wo * cout:], n, H, W, cin, cout, k, stride, pad, dw=dw)
+        return dw[:cout * k * k * cin].view(cout, k, k, cin)
     d = L.WgradDesc(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _pixtab(N, H, W, k, stride, pad, cin, x.device).data_ptr(),
                     N, H, W, cin, cin, cout, cout, k, k, stride, pad)
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
@@ -93,6 +121,11 @@ def conv_dgrad(dy, weight_oihw, N, H, W, cin, cout, k, stride, pad):
     of the taps, so each is a small stride-1 conv over dy (1x1 / 1x2 / 2x1 / 2x2 taps) and `interleave2x2` assembles dX:
     exactly the forward's MFMA work instead of 4x on a zero-stuffed grid.  Other strides: zero stuffing."""
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    per = _image_chunk(N, H * W * max(cin, cout), (Ho + 1) * (Wo + 1) * cout)
+    if per < N:
+        return torch.cat([conv_dgrad(dy[i0 * Ho * Wo * cout:(i0 + min(per, N - i0)) * Ho * Wo * cout], weight_oihw,
+                                     min(per, N - i0), H, W, cin, cout, k, stride, pad)[:min(per, N - i0) * H * W * cin]
+                          for i0 in range(0, N, per)])
     flops = 2.0 * N * Ho * Wo * cout * k * k * cin                                       # algorithmic
     w = weight_oihw.detach()
     if stride == 2 and (k, pad) in ((3, 1), (1, 0)):

@@ -36,6 +36,28 @@ def test_conv_wgrad_dgrad(gpu, N, H, W, cin, cout, k, stride, pad):
     assert rel_err(dx[:N * H * W * cin].view(N, H, W, cin).permute(0, 3, 1, 2).cpu(), x.grad) <= 2e-5
 
 
+def test_conv_helpers_chunk_past_the_buffer_limit(gpu, monkeypatch):
+    """Batches whose tensors would pass the kernels' 2 GiB limit run as image chunks: same results (limit shrunk here)."""
+    N, H, W, cin, cout, k, stride, pad = 5, 12, 10, 64, 128, 3, 2, 1
+    x = synth.normal((N, cin, H, W), 1)
+    w = synth.normal((cout, cin, k, k), 2, 0, 0.05)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    dy = synth.normal((N, cout, Ho, Wo), 3)
+    xg, dyg, wg = nhwc(x), nhwc(dy), w.cuda()
+    w_ohwi = wg.permute(0, 2, 3, 1).contiguous().view(-1)
+
+    def run():
+        y, _, _ = training.conv_raw(xg, w_ohwi, None, N, H, W, cin, cout, k, stride, pad)
+        return (y.clone(), training.conv_wgrad(xg, dyg, N, H, W, cin, cout, k, stride, pad).clone(),
+                training.conv_dgrad(dyg, wg, N, H, W, cin, cout, k, stride, pad)[:N * H * W * cin].clone())
+    whole = run()
+    monkeypatch.setattr(training, "BUF_LIMIT", 2 * H * W * max(cin, cout) * 4 + 64)        # two images per launch
+    assert training._image_chunk(N, H * W * max(cin, cout)) == 2
+    parts = run()
+    assert torch.equal(parts[0], whole[0]) and torch.equal(parts[2], whole[2])
+    assert rel_err(parts[1].cpu(), whole[1].cpu()) <= 1e-5                                   # atomics: order differs
+
+
 @pytest.mark.parametrize("N,H,W", [(2, 64, 96), (1, 37, 52), (3, 30, 33), (1, 448, 800)])
 def test_stem_weight_gradient_direct_kernel(gpu, N, H, W):
     """bevf_stem_wgrad_f32 (no im2col) against autograd of the 7x7 stride-2 conv; W % 4 != 0 takes the scalar staging."""
