@@ -1,0 +1,61 @@
+"""Host-side logic that needs no GPU: launch-limit chunking, conv-mode switch, checkpoint dict layout, refusal of CPU
+tensors by the new entry points."""
+import pytest
+import torch
+
+from bevfusion_multimodal_3d_object_detection_amd import _lib as L
+from bevfusion_multimodal_3d_object_detection_amd import checkpoint, engine, fusion, preprocess, synth, training
+
+
+def test_image_chunks_are_balanced_and_respect_the_limit(monkeypatch):
+    assert training._image_chunk(48, 225 * 400 * 64) == 48                       # config 4 fits one launch
+    assert training._image_chunk(96, 225 * 400 * 64) == 48                       # 2.2 GB of layer-1 input: two chunks
+    monkeypatch.setattr(training, "BUF_LIMIT", 1000 * 4)
+    for n in range(1, 40):
+        per = training._image_chunk(n, 300)
+        assert 1 <= per <= 3 or n <= 3
+        assert per * 300 * 4 <= 1000 * 4
+        assert -(-n // per) == -(-n // 3)                                         # as few launches as the limit allows
+
+
+def test_conv_mode_switch_validates_and_changes_engine_signature():
+    assert engine.conv_mode() == "f32"
+    with pytest.raises(ValueError):
+        engine.set_conv_mode("bf16x9")
+    m = fusion.create_detector("camera_only", "bev", "centernet", bev_h=16, bev_w=16)
+    eng = m.camera_encoder._eng()
+    before = eng._signature()
+    engine.set_conv_mode("f32x3")
+    try:
+        assert eng._signature() != before                                         # next forward repacks
+    finally:
+        engine.set_conv_mode("f32")
+    assert eng._signature() == before
+
+
+def test_checkpoint_dict_layout_on_cpu(tmp_path):
+    m = fusion.create_detector("camera_only", "bev", "centernet", bev_h=16, bev_w=16)
+    synth.fill_state_dict_(m, 3)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, weight_decay=0.01)
+    path = tmp_path / "best_model.pth"
+    checkpoint.save_checkpoint(path, m, opt, epoch=7, config={"use_camera": True}, best_map=0.5)
+    raw = torch.load(path, weights_only=True)
+    assert set(raw) == {"epoch", "model_state_dict", "optimizer_state_dict", "config", "best_map"}     # ref train_detect.py:786-792
+    assert list(raw["model_state_dict"]) == list(m.state_dict())
+    m2 = fusion.create_detector("camera_only", "bev", "centernet", bev_h=16, bev_w=16)
+    ck = checkpoint.load_checkpoint(path, m2)
+    assert ck["epoch"] == 7 and ck["best_map"] == 0.5
+    for a, b in zip(m.state_dict().values(), m2.state_dict().values()):
+        assert torch.equal(a, b)
+    torch.save({"weights": 1}, tmp_path / "other.pth")
+    with pytest.raises(KeyError):
+        checkpoint.load_checkpoint(tmp_path / "other.pth")
+
+
+def test_new_entry_points_refuse_cpu_tensors():
+    with pytest.raises(L.BevfError):
+        preprocess.preprocess_camera_images(torch.zeros(1, 8, 8, 3, dtype=torch.uint8))
+    with pytest.raises(L.BevfError):
+        preprocess.filter_pad_lidar(torch.zeros(10, 4))
+    with pytest.raises(L.BevfError):
+        preprocess.preprocess_camera_images(torch.zeros(1, 8, 8, 3))                          # not uint8
