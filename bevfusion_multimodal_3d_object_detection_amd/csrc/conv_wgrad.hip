@@ -204,12 +204,16 @@ int launch_wgrad(WgradArgs a, hipStream_t st) {
   a.tilesI = (a.Cout + BI - 1) / BI;
   a.tilesJ = (a.K + BJ - 1) / BJ;
   const int steps = (a.M + PS - 1) / PS;
-  int splits = 1024 / (a.tilesI * a.tilesJ);            // ~4 workgroups per CU in flight
+  constexpr size_t lds_bytes = size_t(2) * PS * (BI + BJ) * sizeof(float);
+  // One round of the chip: as many workgroups as are resident at once (LDS-bound: 2 or 3 per CU).  Measured with
+  // in-kernel stamps: the K loop runs at 92-100 % of the MFMA rate, but 1020 equal workgroups on 768 slots left the
+  // second round a third full (-25 %); fewer, longer workgroups also halve the atomics' share.
+  const int resident = 256 * (int)((160 * 1024) / lds_bytes);
+  int splits = resident / (a.tilesI * a.tilesJ);
   if (splits < 1) splits = 1;
   if (splits > steps) splits = steps;
   a.steps_per_split = (steps + splits - 1) / splits;
   splits = (steps + a.steps_per_split - 1) / a.steps_per_split;
-  constexpr size_t lds_bytes = size_t(2) * PS * (BI + BJ) * sizeof(float);
   hipLaunchKernelGGL((conv_wgrad_f32<BI, BJ, WI, WJ>), dim3(a.tilesI * a.tilesJ * splits), dim3(256), lds_bytes, st, a);
   return bevf_check_launch("bevf_conv2d_wgrad_f32");
 }
