@@ -115,17 +115,21 @@ def _dgrad_conv(src, filt_oihw_sub, N, Hs, Ws, cin, cout, kh, kw):
     return out, ho, wo
 
 
-def conv_dgrad(dy, weight_oihw, N, H, W, cin, cout, k, stride, pad):
+def conv_dgrad(dy, weight_oihw, N, H, W, cin, cout, k, stride, pad, add=None):
     """dX [N*H*W*cin] = conv_transpose(dy, W).  Stride 1: the forward kernel on dy with the flipped filter.  Stride 2
     (3x3 pad 1, or 1x1 pad 0 -- the ResNet shapes): the four input-parity classes (ih&1, iw&1) each see a fixed subset
     of the taps, so each is a small stride-1 conv over dy (1x1 / 1x2 / 2x1 / 2x2 taps) and `interleave2x2` assembles dX:
-    exactly the forward's MFMA work instead of 4x on a zero-stuffed grid.  Other strides: zero stuffing."""
+    exactly the forward's MFMA work instead of 4x on a zero-stuffed grid.  Other strides: zero stuffing.
+    `add` [N*H*W*cin]: a gradient to sum into dX (the skip connection's), fused into the conv epilogue when stride 1."""
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     per = _image_chunk(N, H * W * max(cin, cout), (Ho + 1) * (Wo + 1) * cout)
-    if per < N:
-        return torch.cat([conv_dgrad(dy[i0 * Ho * Wo * cout:(i0 + min(per, N - i0)) * Ho * Wo * cout], weight_oihw,
-                                     min(per, N - i0), H, W, cin, cout, k, stride, pad)[:min(per, N - i0) * H * W * cin]
-                          for i0 in range(0, N, per)])
+    if per < N or (add is not None and stride != 1):
+        dx = torch.cat([conv_dgrad(dy[i0 * Ho * Wo * cout:(i0 + min(per, N - i0)) * Ho * Wo * cout], weight_oihw,
+                                   min(per, N - i0), H, W, cin, cout, k, stride, pad)[:min(per, N - i0) * H * W * cin]
+                        for i0 in range(0, N, per)]) if per < N else conv_dgrad(dy, weight_oihw, N, H, W, cin, cout, k, stride, pad)
+        if add is not None:
+            add_(dx, add, min(dx.numel(), add.numel()))
+        return dx
     flops = 2.0 * N * Ho * Wo * cout * k * k * cin                                       # algorithmic
     w = weight_oihw.detach()
     if stride == 2 and (k, pad) in ((3, 1), (1, 0)):
@@ -161,7 +165,10 @@ def conv_dgrad(dy, weight_oihw, N, H, W, cin, cout, k, stride, pad):
     dx = _new(N * H * W * cin, dy.device)
     with E._span("conv_dgrad_f32", flops=flops):
         L.conv2d_nhwc(src, wt, None, None, dx, N=N, H=sh, W=sw, Cin=cout, x_cs=cout, Cout=cin, y_cs=cin, KH=k, KW=k,
-                      stride=1, pad=k - 1 - pad, relu=False)
+                      stride=1, pad=k - 1 - pad, relu=False, res=add if stride == 1 else None,
+                      res_cs=cin if (add is not None and stride == 1) else 0)
+    if add is not None and stride != 1:
+        add_(dx, add, min(dx.numel(), add.numel()))
     return dx
 
 
@@ -290,8 +297,9 @@ class ConvBNLayer:
         self.has_res = res is not None
         return y, Ho, Wo
 
-    def backward(self, dy, sink: GradSink, need_dx=True):
-        """dy: gradient of the layer output (modified in place).  Returns (dx or None, d_res or None)."""
+    def backward(self, dy, sink: GradSink, need_dx=True, add=None):
+        """dy: gradient of the layer output (modified in place).  Returns (dx or None, d_res or None); `add` is summed
+        into dx (skip-connection gradient, fused into the data-gradient conv's epilogue when it can be)."""
         d_res = None
         if self.bn is None:
             if self.relu:
@@ -312,7 +320,7 @@ class ConvBNLayer:
         dx = None
         if need_dx:
             w4 = w if w.dim() == 4 else w.unsqueeze(-1)
-            dx = conv_dgrad(dxraw, w4, self.N, self.H, self.W, self.cin, self.cout, self.k, self.stride, self.pad)
+            dx = conv_dgrad(dxraw, w4, self.N, self.H, self.W, self.cin, self.cout, self.k, self.stride, self.pad, add=add)
         return dx, d_res
 
 
@@ -419,12 +427,12 @@ class DetectorTape:
         d, _ = self.proj.backward(dfeat, sink)
         for i, (c1, c2, down) in enumerate(reversed(self.blocks)):
             dt, d_res = c2.backward(d, sink)                   # d_res: gradient reaching the skip connection
-            dx, _ = c1.backward(dt, sink)
             if down is not None:
+                dx, _ = c1.backward(dt, sink)
                 dd, _ = down.backward(d_res, sink)
                 add_(dx, dd, dx.numel())
             else:
-                add_(dx, d_res, min(dx.numel(), d_res.numel()))
+                dx, _ = c1.backward(dt, sink, add=d_res)       # identity skip: summed in the dgrad conv's epilogue
             d = dx
             if i % 2 == 1:
                 sink.ready()                                   # one ResNet stage done: its gradients can travel
