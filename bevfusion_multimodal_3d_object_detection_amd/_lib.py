@@ -116,6 +116,8 @@ SIGNATURES = {
     "bevf_split_weights_f32x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "bevf_conv2d_nhwc_f32x3": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "bevf_conv2d_nhwc_bf16": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "bevf_stem_pack_bf16": (C.c_int, [C.c_void_p] * 3),
+    "bevf_stem_conv7x7_bf16mma": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_stem_conv7x7_bf16out": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_maxpool3x3s2_nhwc_bf16": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_pointwise_smallk_bf16out": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
@@ -244,6 +246,21 @@ def split_weights_f32x3(w: torch.Tensor) -> torch.Tensor:
     out = torch.empty(3 * w.numel(), dtype=torch.bfloat16, device=w.device)
     _check(lib().bevf_split_weights_f32x3(_pc(w), _p(out, torch.bfloat16), w.numel(), _stream()), "bevf_split_weights_f32x3")
     return out
+
+
+def stem_pack_bf16(w_oihw: torch.Tensor) -> torch.Tensor:
+    out = torch.empty(64 * 176, dtype=torch.bfloat16, device=w_oihw.device)
+    _check(lib().bevf_stem_pack_bf16(_pc(w_oihw.float().contiguous()), _p(out, torch.bfloat16), _stream()), "bevf_stem_pack_bf16")
+    return out
+
+
+def stem_conv7x7_bf16mma(x: torch.Tensor, w_packed: torch.Tensor, scale, shift, y: torch.Tensor, N: int, H: int, W: int,
+                         relu: bool = True):
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if x.numel() != N * 3 * H * W or w_packed.numel() != 64 * 176 or y.numel() < N * Ho * Wo * 64:
+        raise BevfError("stem bf16: buffer sizes do not match N,H,W")
+    _check(lib().bevf_stem_conv7x7_bf16mma(_pc(x), _pc(w_packed, torch.bfloat16), _pc(scale), _pc(shift), _p(y, torch.bfloat16),
+                                           N, H, W, int(relu), _stream()), "bevf_stem_conv7x7_bf16mma")
 
 
 def stem_conv7x7(x: torch.Tensor, w_packed: torch.Tensor, scale, shift, y: torch.Tensor, N: int, H: int, W: int,

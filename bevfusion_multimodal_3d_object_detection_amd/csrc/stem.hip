@@ -385,3 +385,192 @@ extern "C" int bevf_stem_wgrad_f32(const float* x, const float* dy, float* dw, i
                      Wo, tilesW, tilesH, (W % 4 == 0 && bevf_aligned16(x)) ? 1 : 0);
   return bevf_check_launch("bevf_stem_wgrad_f32");
 }
+
+// ---- bf16 stem (bf16-storage models): 7x7 stride-2 conv on v_mfma_f32_32x32x16_bf16 -----------------------------------
+// The bf16 MFMA wants 8 consecutive k per lane, which the strided patch cannot supply directly.  Per half output row
+// (64 pixels) the workgroup therefore expands the bf16 patch into an explicit column tile in LDS,
+//     col[pixel][k],  k = (c*7 + kh)*8 + kw   (kw = 7 and k >= 168 are zero columns; 176 = 11 MFMA k-groups),
+// with four aligned dword reads + three v_alignbit per (pixel, c, kh) item and one 16-byte write, then runs 11 MFMAs
+// per wave on aligned 16-byte fragments.  The expansion is vector-ALU / LDS work that the fp32 stem could not afford
+// (there every VALU instruction queues behind a 64-cycle MFMA); the bf16 MFMA is 16x faster per flop, so even with the
+// expansion the stem drops from ~24 % to a few % of the bf16 step.
+namespace {
+
+constexpr int KP = 176;                  // padded K (bf16 elements)
+constexpr int CP = 368;                  // row pitch in bytes of the column / weight tiles (176*2 + 16: conflict-free b128)
+constexpr int HP = 64;                   // pixels per expansion (half a tile row)
+
+typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4s __attribute__((ext_vector_type(4)));
+
+template <typename TO>
+__global__ __launch_bounds__(256) void stem_conv7x7_bf16mma(const float* __restrict__ x, const __bf16* __restrict__ w,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             TO* __restrict__ y, int H, int W, int Ho, int Wo, int tilesW,
+                                                             int tilesH, int relu) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // The filter bank only passes through LDS (each wave keeps its fragments in registers), so it shares the column
+  // tile's storage: 44 KB per workgroup, 3 workgroups per CU.
+  char* const col = reinterpret_cast<char*>(smem);                 // [HP][CP]   bf16 column tile
+  char* const wt = col;                                            // [64][CP]   bf16 filter, k contiguous per channel (transient)
+  char* const patch = col + HP * CP;                               // [3][PR][PW] bf16
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tw = blockIdx.x % tilesW;
+  const int th = (blockIdx.x / tilesW) % tilesH;
+  const int n = blockIdx.x / (tilesW * tilesH);
+  const int ow0 = tw * TP, oh0 = th * TH;
+
+  // filter bank [64][176] bf16 -> LDS rows of pitch CP
+  for (int i = tid; i < 64 * (KP / 8); i += 256) {
+    const int ch = i / (KP / 8), q = i - ch * (KP / 8);
+    *reinterpret_cast<u32x4*>(wt + ch * CP + q * 16) = *reinterpret_cast<const u32x4*>(w + (size_t)ch * KP + q * 8);
+  }
+  // patch: fp32 image rows -> bf16 (patch row (c, pr) <-> image row 2*oh0 - 3 + pr, patch col <-> iw = 2*ow0 - 4 + col);
+  // one patch row per wave and pass, 16-byte loads that the descriptor zero-fills outside the image row
+  {
+    const float* img = x + (size_t)n * 3 * H * W;
+    const int iw0 = 2 * ow0 - 4;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const bool vec_ok = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
+    for (int r = wv; r < 3 * PR; r += 4) {
+      const int c = r / PR, pr = r - c * PR;
+      const int ih = 2 * oh0 - 3 + pr;
+      const bool row_ok = (unsigned)ih < (unsigned)H;                      // wave-uniform
+      const float* row = img + ((size_t)c * H + (row_ok ? ih : 0)) * W;
+      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(row), 0, row_ok ? W * 4 : 0, 0x00020000);
+      for (int c4 = lane; c4 < PW / 4; c4 += 64) {
+        const int iw = iw0 + 4 * c4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (vec_ok) {
+          v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, iw >= 0 ? (unsigned)(iw * 4) : 0x80000000u, 0, 0));
+        } else if (row_ok) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if ((unsigned)(iw + j) < (unsigned)W) v[j] = row[iw + j];
+        }
+        bf16x4s b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = (__bf16)v[j];
+        *reinterpret_cast<bf16x4s*>(patch + ((size_t)r * PW + 4 * c4) * 2) = b;
+      }
+    }
+  }
+  __syncthreads();
+
+  const int h = lane >> 5, l31 = lane & 31;
+  const int mi = wave >> 1, ni = wave & 1;                         // wave tile: 32 pixels x 32 channels of the half row
+  const float sc = scale[ni * 32 + l31], sh = shift[ni * 32 + l31];
+  const char* const a_rd = col + (mi * 32 + l31) * CP + h * 16;
+  const char* const b_rd = wt + (ni * 32 + l31) * CP + h * 16;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  constexpr int NG = KP / 16;
+  bf16x8s bfrag[NG];                                               // the wave's filter fragments: read once per tile
+#pragma unroll
+  for (int g = 0; g < NG; ++g) bfrag[g] = *reinterpret_cast<const bf16x8s*>(b_rd + g * 32);
+  __syncthreads();                                                 // filter bank consumed: its storage becomes the column tile
+  if (tid < HP) *reinterpret_cast<u32x4*>(col + tid * CP + 168 * 2) = u32x4{0u, 0u, 0u, 0u};   // zero columns 168..175, once
+  // expansion roles: item i = tid + 256*j <-> (pixel p = i & 63, patch row r = i >> 6); p and the r-step are fixed per thread
+  const int xp = tid & (HP - 1), xr0 = tid >> 6;                   // r = xr0 + 4*j, j < 6 (r < 21)
+
+  for (int ro = 0; ro < TH; ++ro) {
+    const int oh = oh0 + ro;
+    if (oh >= Ho) break;
+    for (int hf = 0; hf < TP / HP; ++hf) {
+      if (ow0 + hf * HP >= Wo) break;
+      // ---- expand: all window reads first, then the shifts and the 16-byte writes -----------------------------------
+      {
+        unsigned d[6][4];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int r = xr0 + 4 * j;
+          if (r < 21) {
+            const int c = r / 7, kh = r - c * 7;
+            const unsigned* src = reinterpret_cast<const unsigned*>(patch + ((size_t)(c * PR + 2 * ro + kh) * PW + 2 * (hf * HP + xp)) * 2);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) d[j][q] = src[q];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int r = xr0 + 4 * j;
+          if (r < 21) {
+            u32x4 o;
+            o[0] = __builtin_amdgcn_alignbit(d[j][1], d[j][0], 16);
+            o[1] = __builtin_amdgcn_alignbit(d[j][2], d[j][1], 16);
+            o[2] = __builtin_amdgcn_alignbit(d[j][3], d[j][2], 16);
+            o[3] = d[j][3] >> 16;                                  // kw = 6, then the zero column kw = 7
+            *reinterpret_cast<u32x4*>(col + xp * CP + r * 16) = o;
+          }
+        }
+      }
+      __syncthreads();
+      // ---- 11 k-groups of 16: fragments first, then the MFMAs back to back --------------------------------------------
+      bf16x8s afrag[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) afrag[g] = *reinterpret_cast<const bf16x8s*>(a_rd + g * 32);
+      f32x16 acc;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[g], bfrag[g], g == 0 ? zero : acc, 0, 0, 0);
+      // ---- epilogue: rows i = pixel, column j = channel ------------------------------------------------------
+      const int px0 = ow0 + hf * HP + mi * 32;
+      const int left = Wo - px0;
+      TO* const ybase = y + ((size_t)(n * Ho + oh) * Wo + px0) * 64 + ni * 32;
+      const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+          ybase, 0, left > 0 ? ((left > 32 ? 32 : left) * 64 - ni * 32) * (int)sizeof(TO) : 0, 0x00020000);
+      const unsigned lane_off = (unsigned)((4 * h * 64 + l31) * (int)sizeof(TO));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ioff = ((r & 3) + 8 * (r >> 2)) * 64 * (int)sizeof(TO);
+        float v = fmaf(acc[r], sc, sh);
+        if (relu) v = fmaxf(v, 0.f);
+        if constexpr (sizeof(TO) == 4)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, lane_off + ioff, 0, 0);
+        else
+          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)v), ry, lane_off + ioff, 0, 0);
+      }
+      __syncthreads();                                             // column tile free for the next expansion
+    }
+  }
+}
+
+constexpr size_t kStemBf16Lds = (size_t)HP * CP + (size_t)3 * PR * PW * 2;
+
+__global__ __launch_bounds__(256) void stem_pack_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 64 * KP) return;
+  const int ch = i / KP, k = i - ch * KP, r = k >> 3, kw = k & 7;
+  float v = 0.f;
+  if (r < 21 && kw < 7) v = w[(ch * 21 + r) * 7 + kw];
+  out[i] = (__bf16)v;
+}
+
+}  // namespace
+
+// Packs the fp32 OIHW stem filter (64,3,7,7) into the bf16 [64][176] bank of the bf16 stem: k = (c*7+kh)*8 + kw.
+extern "C" int bevf_stem_pack_bf16(const float* w_oihw, void* packed, void* stream) {
+  BEVF_REQUIRE(w_oihw && packed, "stem_pack_bf16: null pointer");
+  hipLaunchKernelGGL(stem_pack_bf16_kernel, dim3((64 * KP + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), w_oihw,
+                     static_cast<__bf16*>(packed));
+  return bevf_check_launch("bevf_stem_pack_bf16");
+}
+
+extern "C" int bevf_stem_conv7x7_bf16mma(const float* x, const void* w_packed, const float* scale, const float* shift, void* y,
+                                         int N, int H, int W, int relu, void* stream) {
+  BEVF_REQUIRE(x && w_packed && scale && shift && y, "stem bf16: null pointer");
+  BEVF_REQUIRE(bevf_aligned16(w_packed) && bevf_aligned16(y), "stem bf16: unaligned");
+  BEVF_REQUIRE(N > 0 && H >= 1 && W >= 1, "stem bf16: empty shape");
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+  const int tilesW = (Wo + TP - 1) / TP, tilesH = (Ho + TH - 1) / TH;
+  const long long grid = (long long)N * tilesH * tilesW;
+  BEVF_REQUIRE(grid < (1ll << 31), "stem bf16: grid too large");
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_conv7x7_bf16mma<__bf16>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStemBf16Lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(stem_conv7x7_bf16mma<__bf16>, dim3((unsigned)grid), dim3(256), kStemBf16Lds,
+                     static_cast<hipStream_t>(stream), x, static_cast<const __bf16*>(w_packed), scale, shift,
+                     static_cast<__bf16*>(y), H, W, Ho, Wo, tilesW, tilesH, relu);
+  return bevf_check_launch("bevf_stem_conv7x7_bf16mma");
+}

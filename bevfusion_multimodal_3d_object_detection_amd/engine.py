@@ -209,6 +209,7 @@ class CameraEncoderEngine(_Engine):
         packed[:147] = w.reshape(64, 147).t()
         self.stem_w = packed.contiguous().view(-1)
         self.stem_scale, self.stem_shift = _bn_fold(None, m.bn1, 64, w.device)
+        self.stem_w_bf16 = L.stem_pack_bf16(w) if self.dtype == torch.bfloat16 else None   # bf16 models: bf16-MFMA stem
         self.blocks = []
         for layer in (m.layer1, m.layer2, m.layer3):
             for blk in layer:
@@ -246,7 +247,10 @@ class CameraEncoderEngine(_Engine):
         H2, W2 = (H1 - 1) // 2 + 1, (W1 - 1) // 2 + 1
         stem = self.buf("stem", N * H1 * W1 * 64)
         with _span("stem_conv7x7_f32", flops=2.0 * N * H1 * W1 * 64 * 147):
-            L.stem_conv7x7(x, self.stem_w, self.stem_scale, self.stem_shift, stem, N, H, W)
+            if self.stem_w_bf16 is not None:
+                L.stem_conv7x7_bf16mma(x.float(), self.stem_w_bf16, self.stem_scale, self.stem_shift, stem, N, H, W)
+            else:
+                L.stem_conv7x7(x, self.stem_w, self.stem_scale, self.stem_shift, stem, N, H, W)
         cur = self.buf("act0", N * H2 * W2 * 64)
         L.maxpool3x3s2(stem, cur, N, H1, W1, 64)
         h, w = H2, W2

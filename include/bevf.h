@@ -258,7 +258,13 @@ int bevf_conv2d_nhwc_bf16(const bevf_conv_desc* d, void* stream);
 int bevf_split_weights_f32x3(const float* w, void* planes, size_t n, void* stream);
 int bevf_conv2d_nhwc_f32x3(const bevf_conv_desc* d, void* stream);
 int bevf_stem_conv7x7_bf16out(const float* x, const float* w, const float* scale, const float* shift, void* y, int N,
-                              int H, int W, int relu, void* stream);     /* fp32 image + fp32 MFMA, bf16 NHWC out */
+                              int H, int W, int relu, void* stream);
+/* bf16 stem on the bf16 MFMA (bf16-storage models): x fp32 NCHW (rounded to bf16 while it is staged), filter bank
+ * bf16 [64][176] from bevf_stem_pack_bf16 (k = (c*7+kh)*8 + kw, zero columns for kw = 7 and k >= 168), fp32
+ * accumulate, folded BN + ReLU, bf16 NHWC out.                                                                   */
+int bevf_stem_pack_bf16(const float* w_oihw, void* packed, void* stream);
+int bevf_stem_conv7x7_bf16mma(const float* x, const void* w_packed, const float* scale, const float* shift, void* y,
+                              int N, int H, int W, int relu, void* stream);     /* fp32 image + fp32 MFMA, bf16 NHWC out */
 int bevf_maxpool3x3s2_nhwc_bf16(const void* x, void* y, int N, int H, int W, int C, void* stream);
 int bevf_pointwise_smallk_bf16out(const float* x, const float* w, const float* scale, const float* shift, void* y,
                                   int M, int K, int Cout, int relu, void* stream);

@@ -77,3 +77,19 @@ def test_detector_bf16_vs_fp32_oracle_on_bf16_weights(gpu, modality, bev):
     m32.load_state_dict(ora.state_dict())
     o32 = m32.cuda().eval()(imgs.cuda(), pts.cuda(), [r.cuda() for r in radars] if radars else None)
     assert rel_err(out["size"].cpu(), o32["size"].cpu()) <= 3e-2
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 64, 96), (1, 37, 50), (1, 33, 46), (2, 450, 800)])
+def test_stem_bf16_mfma(gpu, N, H, W):
+    """bf16-MFMA stem (column tile expanded in LDS) against fp32 torch on the bf16-rounded image and filter."""
+    x = synth.normal((N, 3, H, W), 1)
+    w = synth.normal((64, 3, 7, 7), 2, 0, (1.0 / 147) ** 0.5)
+    scale, shift = synth.uniform((64,), 3, 0.5, 1.5), synth.normal((64,), 4, 0, 0.3)
+    ref = F.relu(F.conv2d(r16(x), r16(w), None, 2, 3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    Ho, Wo = ref.shape[-2:]
+    wp = L.stem_pack_bf16(w.cuda())
+    y = torch.zeros(N * Ho * Wo * 64, dtype=BF, device=gpu)
+    xg = x.cuda()
+    L.stem_conv7x7_bf16mma(xg, wp, scale.cuda(), shift.cuda(), y, N, H, W, relu=True)
+    got = y.float().view(N, Ho, Wo, 64).permute(0, 3, 1, 2).cpu()
+    assert rel_err(got, ref) <= 4e-3

@@ -29,6 +29,7 @@ names = sys.argv[1].split(",") if len(sys.argv) > 1 else list(SHAPES)
 tiles = [int(t) for t in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1, 2, 3, 4]
 PLAIN = len(sys.argv) > 3 and sys.argv[3] == "plain"      # no scale/shift/relu epilogue
 SPLIT = len(sys.argv) > 3 and sys.argv[3] == "split"      # f32x3 kernel
+BF16 = len(sys.argv) > 3 and sys.argv[3] == "bf16"        # bf16 storage kernel
 for name in names:
     N, H, W, Cin, Cout, k, s, p = SHAPES[name]
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
@@ -37,6 +38,7 @@ for name in names:
     sc, sh = torch.rand(Cout, device=dev) + 0.5, torch.randn(Cout, device=dev)
     if SPLIT: w = L.split_weights_f32x3(w)
     y = torch.empty(N * Ho * Wo * Cout, device=dev)
+    if BF16: x, w, y = x.bfloat16(), w.bfloat16(), y.bfloat16()
     flops = 2.0 * N * Ho * Wo * Cout * k * k * Cin
     res = []
     for t in tiles:
