@@ -159,6 +159,50 @@ __global__ __launch_bounds__(256) void head_tail(const HeadArgs a) {
   }
 }
 
+// Coalesced variant for hc/V a power of two <= 64 (hc = 64: the reference's head): the CH = hc/V lanes of a pixel read
+// consecutive 16-byte chunks of one branch's hidden vector (a wave covers 64/CH pixels per pass, one branch per
+// iteration), accumulate their slice of the branch's outputs and combine with a butterfly over the CH lanes.  The
+// thread-per-pixel form above strides 1280 B between lanes and thrashes L1 (1 TB/s); this one streams.
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void head_tail_coalesced(const HeadArgs a) {
+  constexpr int V = vec16<T>::N, PPW = 64 / CH;
+  extern __shared__ float wl[];   // [ctot][hc] then bias[ctot]
+  const int ctot = a.c[0] + a.c[1] + a.c[2] + a.c[3] + a.c[4];
+  for (int i = threadIdx.x; i < ctot * a.hc; i += 256) wl[i] = a.w[i];
+  for (int i = threadIdx.x; i < ctot; i += 256) wl[ctot * a.hc + i] = a.bias[i];
+  __syncthreads();
+  const float* bl = wl + ctot * a.hc;
+  const int lane = threadIdx.x & 63, sub = lane % CH, pw = lane / CH;
+  const long long total = (long long)a.B * a.P;
+  const long long wave_global = (blockIdx.x * 256ll + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * 256) >> 6;
+  for (long long base = wave_global * PPW; base < total; base += nwaves * PPW) {
+    const long long pix = base + pw;
+    const bool ok = pix < total;
+    const long long pc = ok ? pix : total - 1;
+    const int b = (int)(pc / a.P), p = (int)(pc - (long long)b * a.P);
+    const T* hp = static_cast<const T*>(a.hid) + (size_t)pc * 5 * a.hc + sub * V;
+    int oc = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      float hv[V];
+      load16(hp + k * a.hc, hv);
+      for (int c = 0; c < a.c[k]; ++c, ++oc) {
+        const float* wr = wl + oc * a.hc + sub * V;
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < V; ++q) acc = fmaf(hv[q], wr[q], acc);
+#pragma unroll
+        for (int s = 1; s < CH; s <<= 1) acc += __shfl_xor(acc, s);
+        if (sub == 0 && ok) {
+          float v = acc + bl[oc];
+          if (oc < a.n_sigmoid) v = 1.f / (1.f + expf(-v));
+          a.out[k][((size_t)b * a.c[k] + c) * a.P + p] = v;
+        }
+      }
+    }
+  }
+}
+
 // [N][C][P] -> [N][P][y_cs] and back, 32x32 tiles through LDS (both sides coalesced)
 __global__ __launch_bounds__(256) void nchw_to_nhwc(const float* __restrict__ x, float* __restrict__ y, int C, int P,
                                                      int y_cs) {
@@ -292,8 +336,19 @@ static int head_tail_entry(const bevf_head_desc* d, void* stream) {
   }
   const size_t lds = (size_t)ctot * (d->hc + 1) * sizeof(float);
   BEVF_REQUIRE(lds <= 64 * 1024, "head_tail: weights need %zu B of LDS", lds);
-  hipLaunchKernelGGL(head_tail<T>, dim3(stream_grid((long long)d->B * d->P)), dim3(256), lds,
-                     static_cast<hipStream_t>(stream), a);
+  constexpr int V = vec16<T>::N;
+  if (d->hc == 16 * V) {                                  // hc = 64 (fp32) / 128 (bf16): 16 lanes per pixel
+    const long long waves = ((long long)d->B * d->P + 3) / 4;
+    hipLaunchKernelGGL((head_tail_coalesced<T, 16>), dim3(stream_grid(waves * 64)), dim3(256), lds,
+                       static_cast<hipStream_t>(stream), a);
+  } else if (d->hc == 8 * V) {                            // hc = 64 in bf16: 8 lanes per pixel
+    const long long waves = ((long long)d->B * d->P + 7) / 8;
+    hipLaunchKernelGGL((head_tail_coalesced<T, 8>), dim3(stream_grid(waves * 64)), dim3(256), lds,
+                       static_cast<hipStream_t>(stream), a);
+  } else {
+    hipLaunchKernelGGL(head_tail<T>, dim3(stream_grid((long long)d->B * d->P)), dim3(256), lds,
+                       static_cast<hipStream_t>(stream), a);
+  }
   return bevf_check_launch("bevf_head_tail");
 }
 extern "C" int bevf_head_tail_f32(const bevf_head_desc* d, void* stream) { return head_tail_entry<float>(d, stream); }
