@@ -379,6 +379,14 @@ int conv_entry(const bevf_conv_desc* d, void* stream) {
     const double tail = tail_rows > 0 ? rounds((double)((tail_rows + 63) / 64) * ((d->Cout + 63) / 64), 5) * 64 * 64 * 5 / 0.95 : 0.0;
     c128 = big > 0 ? rounds((double)big * tn, 2) * 128 * 128 * 2 + tail : 1e300;
   }
+  // bf16: the K loop is bound by LDS reads, not by the MFMA pipe, so the shapes with 64x64 wave tiles (twice the MFMAs per
+  // fragment read) win by more than their occupancy costs them (tools/conv_bench.py ... bf16: 128x128 +4..15 % on the
+  // Cout >= 128 layers, 256x64 +25 % on Cout = 64)
+  if (sizeof(T) == 2) {
+    c128 *= 0.85;
+    if (d->Cout <= 64 && rounds(wgs(256, 64), 2) * 256 * 64 * 2 * 0.8 <= (c128x64 < c64 ? c128x64 : c64))
+      return launch<T, 256, 64, 64, 64>(a, st);
+  }
   if (c128 <= c128x64 && c128 <= c64) {
     if (big == (int)((M + 127) / 128)) return launch<T, 128, 128, 64, 64>(a, st);
     return launch_hybrid<T, 128, 128, 64, 64>(a, big, st);
