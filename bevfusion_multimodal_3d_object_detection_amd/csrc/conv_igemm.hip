@@ -306,13 +306,13 @@ int launch_hybrid(const ConvArgs& a0, int big_mtiles, hipStream_t st) {
 
 constexpr int kResidentBig = 512;     // 256 CUs x 2 workgroups (64-80 KB of LDS each)
 
-// Rows that big tiles should cover so that they fill whole rounds of the chip; the rest goes to
-// 64x64 tiles.  Returns the number of big M-tiles (0 = all small, tilesM = all big).
-static int split_big_mtiles(long long M, int BM, int tilesN_big) {
+// Rows that big tiles should cover so that they fill whole rounds of the chip (`resident` workgroups at once); the
+// rest goes to 64x64 tiles.  Returns the number of big M-tiles (0 = all small, tilesM = all big).
+static int split_big_mtiles(long long M, int BM, int tilesN_big, int resident = kResidentBig) {
   const int tilesM = (int)((M + BM - 1) / BM);
   const long long nb = (long long)tilesM * tilesN_big;
-  const long long rem = nb % kResidentBig;
-  if (rem == 0 || rem >= (kResidentBig * 3) / 4) return tilesM;          // last round is (nearly) full anyway
+  const long long rem = nb % resident;
+  if (rem == 0 || rem >= (resident * 3) / 4) return tilesM;              // last round is (nearly) full anyway
   const long long full = nb - rem;
   return (int)(full / tilesN_big);                                       // whole rounds only (may be 0)
 }
@@ -360,6 +360,7 @@ int conv_entry(const bevf_conv_desc* d, void* stream) {
     case 4: return launch<T, 64, 64, 32, 32>(a, st);
     case 5: return launch_hybrid<T, 128, 128, 64, 64>(a, (int)(M / 128) / 2, st);     // tests: forced mid split
     case 6: return launch_hybrid<T, 256, 64, 64, 64>(a, (int)(M / 256) / 2, st);
+    case 7: return launch_hybrid<T, 128, 64, 64, 32>(a, (int)(M / 128) / 2, st);
     default: bevf_set_error("conv: unknown tile variant %d", d->tile); return BEVF_ERR_ARG;
   }
   // auto: a small cost model over the tile shapes.  A CU runs `per_cu` workgroups of a shape at once (LDS-bound),
@@ -391,6 +392,17 @@ int conv_entry(const bevf_conv_desc* d, void* stream) {
     if (big == (int)((M + 127) / 128)) return launch<T, 128, 128, 64, 64>(a, st);
     return launch_hybrid<T, 128, 128, 64, 64>(a, big, st);
   }
+  // same wave-quantisation fix for the 128x64 shape (3 workgroups per CU = 768 at once): matters for small M
+  // (B = 1: layer 1 is 1055 tiles = 1.37 rounds; the tail as 64x64 tiles costs half a round instead of a whole one)
+  const int tn64 = (d->Cout + 63) / 64;
+  const int big64 = split_big_mtiles(M, 128, tn64, 768);
+  double hyb64 = 1e300;
+  if (big64 > 0 && big64 < (int)((M + 127) / 128)) {
+    const long long tail_rows = M - (long long)big64 * 128;
+    hyb64 = rounds((double)big64 * tn64, 3) * 128 * 64 * 3 / 0.98 +
+            rounds((double)((tail_rows + 63) / 64) * tn64, 3) * 64 * 64 * 3 / 0.95;
+  }
+  if (hyb64 < c128x64 && hyb64 < c64) return launch_hybrid<T, 128, 64, 64, 32>(a, big64, st);
   if (c128x64 <= c64) return launch<T, 128, 64, 64, 32>(a, st);
   return launch<T, 64, 64, 32, 32>(a, st);
 }

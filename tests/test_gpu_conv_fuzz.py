@@ -27,7 +27,7 @@ def _cases(n, seed):
         out.append(dict(N=N, H=H, W=W, cin=cin, cout=cout, kh=kh, kw=kw, stride=stride, pad=pad,
                         x_cs=cin + int(rs.choice([0, 0, 32, 64])), y_cs=cout + int(rs.choice([0, 0, 4, 60])),
                         res=bool(rs.randint(0, 2)), relu=bool(rs.randint(0, 2)), affine=bool(rs.randint(0, 2)),
-                        tile=int(rs.choice([0, 0, 1, 2, 3, 4, 5, 6])), seed=int(rs.randint(1, 1 << 20))))
+                        tile=int(rs.choice([0, 0, 1, 2, 3, 4, 5, 6, 7])), seed=int(rs.randint(1, 1 << 20))))
     return out
 
 

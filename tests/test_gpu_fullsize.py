@@ -65,7 +65,7 @@ def test_full_size_conv_linearity_and_tile_invariance(gpu):
     x = synth.normal((N * H * W * C,), 1).cuda()
     w = synth.normal((C * 9 * C,), 2, 0, 0.04).cuda()
     outs = []
-    for tile in (0, 1, 2, 3, 4, 5, 6):
+    for tile in (0, 1, 2, 3, 4, 5, 6, 7):
         y = torch.empty(N * H * W * C, device=gpu)
         L.conv2d_nhwc(x, w, None, None, y, N=N, H=H, W=W, Cin=C, x_cs=C, Cout=C, y_cs=C, KH=3, KW=3, stride=1, pad=1,
                       relu=False, tile=tile)
