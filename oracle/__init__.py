@@ -19,4 +19,9 @@ Pinning status
   `torchvision.models` so that the reference's own encoders.py / fusion.py run on
   top of it.  The trunk is anchored by the reference's published parameter counts
   (demo.ipynb:419,519) and output shapes (demo.ipynb cell 6).
+* `ref_voxelize.py` (the reference has no voxel assignment) and `ref_preprocess.py` (the dataset's per-sample work:
+  the image leg runs through Pillow itself, the LiDAR leg through numpy) restate behaviour for which the reference's
+  tests hold no vectors: **parity unpinned by the reference**, pinned by Pillow / numpy / the sequential definition.
+* The evaluation metrics are not restated here at all: `tests/golden/metrics.json` is minted from the reference's own
+  `src/utils_v2.py` by `tests/golden/make_golden_metrics.py`.
 """
