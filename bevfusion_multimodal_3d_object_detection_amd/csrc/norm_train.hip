@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dy
       f32x4 g[4], xv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        g[u] = *reinterpret_cast<const f32x4*>(dy + (size_t)(m + u * step) * C + c);
+        g[u] = dy ? *reinterpret_cast<const f32x4*>(dy + (size_t)(m + u * step) * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
         xv[u] = *reinterpret_cast<const f32x4*>(x + (size_t)(m + u * step) * cs + c);
       }
 #pragma unroll
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dy
       }
     }
     for (; m < M; m += step) {
-      const f32x4 g = *reinterpret_cast<const f32x4*>(dy + (size_t)m * C + c);
+      const f32x4 g = dy ? *reinterpret_cast<const f32x4*>(dy + (size_t)m * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
       const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)m * cs + c);
       f32x4 o;
 #pragma unroll
@@ -336,6 +336,40 @@ __global__ __launch_bounds__(256) void bn_update_running(const float* __restrict
   if (c >= C) return;
   rmean[c] = fmaf(mom, mean[c], rmean[c] * keep);
   rvar[c] = fmaf(mom_unbiased, var[c], rvar[c] * keep);
+}
+
+// ---- BatchNorm backward fed by a max over rows (PointNet's last layer) ---------------------------------------------------
+// The gradient of y = relu(bn(x)) arriving from g[b][c] = max_n y[b][n][c] is non-zero in ONE row per (frame, channel).
+// Instead of scattering it into a dense [M][C] tensor and reducing that again, the per-channel sums are gathered from
+// the B*C non-zeros, the dense part of dx is written without reading any dy, and the B*C entries are added afterwards.
+__global__ __launch_bounds__(256) void gmax_bn_sums(const float* __restrict__ dg, const float* __restrict__ gmax,
+                                                     const int* __restrict__ idx, const float* __restrict__ x,
+                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                     float* __restrict__ dgm, float* __restrict__ s_dy, float* __restrict__ s_dyx,
+                                                     int B, int P, int C, int cs) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float mu = mean[c], is = invstd[c];
+  double a1 = 0, a2 = 0;
+  for (int b = 0; b < B; ++b) {
+    const float g = gmax[(size_t)b * C + c] > 0.f ? dg[(size_t)b * C + c] : 0.f;      // ReLU: relu'(0) = 0, as torch
+    dgm[(size_t)b * C + c] = g;
+    const float xv = x[((size_t)b * P + idx[(size_t)b * C + c]) * cs + c];
+    a1 += g;
+    a2 += (double)g * ((xv - mu) * is);
+  }
+  s_dy[c] = (float)a1;
+  s_dyx[c] = (float)a2;
+}
+
+__global__ __launch_bounds__(256) void gmax_bn_scatter(const float* __restrict__ dgm, const int* __restrict__ idx,
+                                                        const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                        float* __restrict__ dx, int P, int C, int cs, long long total) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= total) return;
+  const long long b = i / C;
+  const int c = (int)(i - b * C);
+  dx[((size_t)b * P + idx[i]) * cs + c] += (gamma ? gamma[c] : 1.f) * invstd[c] * dgm[i];
 }
 
 static inline unsigned row_grid(long long M, int C) {      // workgroups for the row-streaming kernels
@@ -402,4 +436,25 @@ extern "C" int bevf_bn_backward_f32(float* dy, const float* y, const float* x, c
     hipLaunchKernelGGL(bn_bwd_apply, dim3(row_grid(M, C)), dim3(256), 0, st, dy, x, mean, invstd, gamma,
                        dbeta, dgamma, dx, (long long)M, C, cs);
   return bevf_check_launch("bevf_bn_backward_f32");
+}
+
+// Backward of y = relu(batchnorm(x)) followed by a max over the P rows of each of B groups (ref src/encoders.py:296-299
+// in training mode): dg [B][C] gradient of the max, gmax its forward value, idx its argmax row.  Writes dgamma, dbeta and
+// the dense dx [B*P][cs]; dgm [B][C] is scratch.  Equivalent to group_max_bwd + bn_backward without the dense dy.
+extern "C" int bevf_gmax_bn_backward_f32(const float* dg, const float* gmax, const int32_t* idx, const float* x,
+                                         const float* mean, const float* invstd, const float* gamma, float* dgm,
+                                         float* dgamma, float* dbeta, float* dx, int B, int P, int C, int cs, void* stream) {
+  BEVF_REQUIRE(dg && gmax && idx && x && mean && invstd && dgm && dgamma && dbeta && dx, "gmax_bn_backward: null pointer");
+  BEVF_REQUIRE(B > 0 && P > 0 && C > 0 && C % 4 == 0 && cs >= C && cs % 4 == 0, "gmax_bn_backward: bad shape");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long M = (long long)B * P;
+  BEVF_REQUIRE(M < (1ll << 31), "gmax_bn_backward: too many rows");
+  hipLaunchKernelGGL(gmax_bn_sums, dim3((C + 255) / 256), dim3(256), 0, st, dg, gmax, idx, x, mean, invstd, dgm, dbeta, dgamma,
+                     B, P, C, cs);
+  hipLaunchKernelGGL(bn_bwd_apply, dim3(row_grid(M, C)), dim3(256), 0, st, (const float*)nullptr, x, mean, invstd, gamma, dbeta,
+                     dgamma, dx, M, C, cs);
+  const long long total = (long long)B * C;
+  hipLaunchKernelGGL(gmax_bn_scatter, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dgm, idx, gamma, invstd, dx, P, C,
+                     cs, total);
+  return bevf_check_launch("bevf_gmax_bn_backward_f32");
 }

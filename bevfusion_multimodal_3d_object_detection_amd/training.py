@@ -337,6 +337,25 @@ class ConvBNLayer:
             sink.add(self.bn.bias, dbeta)
             if self.has_res:
                 d_res = dy                                    # masked by the ReLU in place: gradient of the skip input
+        return self._conv_backward(dxraw, sink, need_dx, add), d_res
+
+    def backward_from_groupmax(self, dg, gmax, idx, B: int, P: int, sink: GradSink):
+        """Backward when this layer's output went straight into a max over the P rows of each of B groups (PointNet's
+        last layer): dg / gmax / idx [B][cout].  The gradient is non-zero in one row per (group, channel), so BatchNorm's
+        sums are gathered from those entries and no dense dY is ever built (bevf_gmax_bn_backward_f32)."""
+        assert self.bn is not None and self.relu and not self.has_res and B * P == self.M
+        st, dev = self.bns, dg.device
+        dgm, dgamma, dbeta = _new(B * self.cout, dev), _new(self.cout, dev), _new(self.cout, dev)
+        dxraw = _new(self.M * self.cout, dev)
+        g = self.bn.weight.data_ptr() if self.bn.weight is not None else None
+        _ck(_lib().bevf_gmax_bn_backward_f32(dg.data_ptr(), gmax.data_ptr(), idx.data_ptr(), st.xraw.data_ptr(), st.mean.data_ptr(),
+                                             st.invstd.data_ptr(), g, dgm.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                             dxraw.data_ptr(), B, P, self.cout, self.cout, _st()), "bevf_gmax_bn_backward_f32")
+        sink.add(self.bn.weight, dgamma[:self.cout])
+        sink.add(self.bn.bias, dbeta[:self.cout])
+        return self._conv_backward(dxraw, sink, True, None)
+
+    def _conv_backward(self, dxraw, sink: GradSink, need_dx=True, add=None):
         if self.conv.bias is not None:
             sink.add(self.conv.bias, colsum(dxraw, self.M, self.cout))
         dw = conv_wgrad(self.x, dxraw, self.N, self.H, self.W, self.cin, self.cout, self.k, self.stride, self.pad)
@@ -346,7 +365,7 @@ class ConvBNLayer:
         if need_dx:
             w4 = w if w.dim() == 4 else w.unsqueeze(-1)
             dx = conv_dgrad(dxraw, w4, self.N, self.H, self.W, self.cin, self.cout, self.k, self.stride, self.pad, add=add)
-        return dx, d_res
+        return dx
 
 
 class LinearLayer:
@@ -502,6 +521,7 @@ class DetectorTape:
         gwork = torch.empty(_lib().bevf_group_max_idx_work_bytes(B, Np, feat), dtype=torch.uint8, device=dev)
         _ck(_lib().bevf_group_max_idx_f32(a.data_ptr(), g.data_ptr(), self.pn_idx.data_ptr(), gwork.data_ptr(), B, Np, feat,
                                           _st()), "bevf_group_max_idx_f32")
+        self.pn_g = g
         return g
 
     def _lidar_backward(self, dg, sink):
@@ -509,10 +529,8 @@ class DetectorTape:
         B, Np, Cc = self.pn_geom
         M = B * Np
         feat = self.pn_layers[-1].cout
-        d = _zeros(M * feat, dg.device)
-        _ck(_lib().bevf_group_max_bwd_f32(dg.data_ptr(), self.pn_idx.data_ptr(), d.data_ptr(), B, Np, feat, _st()),
-            "bevf_group_max_bwd_f32")
-        for lyr in reversed(self.pn_layers):
+        d = self.pn_layers[-1].backward_from_groupmax(dg.contiguous(), self.pn_g, self.pn_idx, B, Np, sink)
+        for lyr in reversed(self.pn_layers[:-1]):
             d, _ = lyr.backward(d, sink)
         draw, dgamma, dbeta = bn_train_backward(d, self.pn_bn0, enc.bn1, relu=True)
         sink.add(enc.bn1.weight, dgamma)

@@ -338,6 +338,12 @@ int bevf_cam_mean_bwd_f32(const float* dy, float* dx, int B, int ncam, int P, in
 size_t bevf_group_max_idx_work_bytes(int G, int P, int C);
 int bevf_group_max_idx_f32(const float* x, float* y, int32_t* idx, void* work, int G, int P, int C, void* stream);
 int bevf_group_max_bwd_f32(const float* dy, const int32_t* idx, float* dx, int G, int P, int C, void* stream); /* dx zero-filled */
+/* Backward of max-over-rows( relu( batchnorm(x) ) ) without the dense intermediate gradient (PointNet's last layer,
+ * ref src/encoders.py:296-299): dg / gmax / idx [B][C] = gradient, value and argmax row of the max; writes dgamma,
+ * dbeta, dx [B*P][cs]; dgm [B][C] scratch.                                                                        */
+int bevf_gmax_bn_backward_f32(const float* dg, const float* gmax, const int32_t* idx, const float* x, const float* mean,
+                              const float* invstd, const float* gamma, float* dgm, float* dgamma, float* dbeta, float* dx,
+                              int B, int P, int C, int cs, void* stream);
 size_t bevf_linear_bwd_work_floats(int B, int K, int O);
 int bevf_linear_bwd_f32(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, float* work,
                         int B, int K, int O, int perm_inner, int perm_outer, void* stream);
