@@ -136,17 +136,37 @@ __global__ __launch_bounds__(256) void cam_mean_bwd(const f32x4* __restrict__ dy
 // ---- group max with argmax, and its scatter backward (dx zero-filled by the caller) -----------------------------------
 // stage 1: one workgroup per (group, chunk of GM_CHUNK points): threads own channel quads, rows are read coalesced
 constexpr int GM_CHUNK = 128;
+// AFFINE: the rows are raw pre-BatchNorm values and the maximum is taken over relu(fma(x, a, b)) with a = gamma*invstd,
+// b = beta - mean*a -- bn_apply's own operations, so value and argmax equal those of the materialised activation.
+template <bool AFFINE>
 __global__ __launch_bounds__(256) void group_max_partial(const float* __restrict__ x, float* __restrict__ pmax,
-                                                          int* __restrict__ pidx, int P, int C, int nchunks) {
+                                                          int* __restrict__ pidx, int P, int C, int nchunks,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta) {
   const int g = blockIdx.x / nchunks, ch = blockIdx.x - g * nchunks;
   const int p0 = ch * GM_CHUNK, p1 = (p0 + GM_CHUNK < P) ? p0 + GM_CHUNK : P;
   const int c4 = C >> 2;
   for (int cq = threadIdx.x; cq < c4; cq += 256) {
+    float fa[4] = {1.f, 1.f, 1.f, 1.f}, fb[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (AFFINE) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        fa[j] = (gamma ? gamma[cq * 4 + j] : 1.f) * invstd[cq * 4 + j];
+        fb[j] = (beta ? beta[cq * 4 + j] : 0.f) - mean[cq * 4 + j] * fa[j];
+      }
+    }
+    auto act = [&](f32x4 v) {
+      if constexpr (AFFINE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], fa[j], fb[j]), 0.f);
+      }
+      return v;
+    };
     const float* src = x + ((size_t)g * P + p0) * C + cq * 4;
-    f32x4 m = *reinterpret_cast<const f32x4*>(src);
+    f32x4 m = act(*reinterpret_cast<const f32x4*>(src));
     int bi[4] = {p0, p0, p0, p0};
     for (int p = p0 + 1; p < p1; ++p) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)(p - p0) * C);
+      const f32x4 v = act(*reinterpret_cast<const f32x4*>(src + (size_t)(p - p0) * C));
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (v[j] > m[j]) { m[j] = v[j]; bi[j] = p; }
@@ -547,10 +567,27 @@ extern "C" int bevf_group_max_idx_f32(const float* x, float* y, int32_t* idx, vo
   const int nchunks = (P + GM_CHUNK - 1) / GM_CHUNK;
   float* pmax = static_cast<float*>(work);
   int* pidx = reinterpret_cast<int*>(pmax + (size_t)G * nchunks * C);
-  hipLaunchKernelGGL(group_max_partial, dim3(G * nchunks), dim3(256), 0, ST, x, pmax, pidx, P, C, nchunks);
+  hipLaunchKernelGGL(group_max_partial<false>, dim3(G * nchunks), dim3(256), 0, ST, x, pmax, pidx, P, C, nchunks,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
   const long long total = (long long)G * C;
   hipLaunchKernelGGL(group_max_final, dim3(ew_grid(total)), dim3(256), 0, ST, pmax, pidx, y, idx, C, nchunks, total);
   return bevf_check_launch("bevf_group_max_idx_f32");
+}
+// max and argmax over the P rows of each group of relu(batchnorm(x)) computed on the fly from the raw rows (training
+// forward of PointNet's last layer: the activation is neither written nor re-read)
+extern "C" int bevf_bn_relu_group_max_idx_f32(const float* x, const float* mean, const float* invstd, const float* gamma,
+                                              const float* beta, float* y, int32_t* idx, void* work, int G, int P, int C,
+                                              void* stream) {
+  BEVF_REQUIRE(x && mean && invstd && y && idx && work && G > 0 && P > 0 && C > 0 && C % 4 == 0, "bn_relu_group_max_idx: bad arguments");
+  BEVF_REQUIRE(bevf_aligned16(x), "bn_relu_group_max_idx: unaligned");
+  const int nchunks = (P + GM_CHUNK - 1) / GM_CHUNK;
+  float* pmax = static_cast<float*>(work);
+  int* pidx = reinterpret_cast<int*>(pmax + (size_t)G * nchunks * C);
+  hipLaunchKernelGGL(group_max_partial<true>, dim3(G * nchunks), dim3(256), 0, ST, x, pmax, pidx, P, C, nchunks, mean, invstd,
+                     gamma, beta);
+  const long long total = (long long)G * C;
+  hipLaunchKernelGGL(group_max_final, dim3(ew_grid(total)), dim3(256), 0, ST, pmax, pidx, y, idx, C, nchunks, total);
+  return bevf_check_launch("bevf_bn_relu_group_max_idx_f32");
 }
 extern "C" int bevf_group_max_bwd_f32(const float* dy, const int32_t* idx, float* dx, int G, int P, int C, void* stream) {
   BEVF_REQUIRE(dy && idx && dx && G > 0 && P > 0 && C > 0, "group_max_bwd: bad arguments");

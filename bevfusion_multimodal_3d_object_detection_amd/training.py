@@ -201,18 +201,21 @@ class _BNState:
     __slots__ = ("mean", "invstd", "xraw", "y", "M", "C", "has_res")
 
 
-def bn_train_forward(xraw, bn: nn.BatchNorm2d, M: int, Cc: int, res=None, relu=True):
+def bn_train_forward(xraw, bn: nn.BatchNorm2d, M: int, Cc: int, res=None, relu=True, apply=True):
+    """Batch statistics (+ running-buffer update) and, unless apply=False, the normalised activation."""
     dev = xraw.device
     work = _new(_lib().bevf_bn_work_floats(Cc), dev)
     mean, var, invstd = _new(Cc, dev), _new(Cc, dev), _new(Cc, dev)
     _ck(_lib().bevf_bn_stats_f32(xraw.data_ptr(), work.data_ptr(), mean.data_ptr(), var.data_ptr(), invstd.data_ptr(),
                                  M, Cc, Cc, float(bn.eps), _st()), "bevf_bn_stats_f32")
-    y = _new(M * Cc, dev)
-    g = bn.weight.data_ptr() if bn.weight is not None else None
-    b = bn.bias.data_ptr() if bn.bias is not None else None
-    _ck(_lib().bevf_bn_apply_f32(xraw.data_ptr(), mean.data_ptr(), invstd.data_ptr(), g, b,
-                                 res.data_ptr() if res is not None else None, y.data_ptr(), M, Cc, Cc, int(relu), _st()),
-        "bevf_bn_apply_f32")
+    y = None
+    if apply:
+        y = _new(M * Cc, dev)
+        g = bn.weight.data_ptr() if bn.weight is not None else None
+        b = bn.bias.data_ptr() if bn.bias is not None else None
+        _ck(_lib().bevf_bn_apply_f32(xraw.data_ptr(), mean.data_ptr(), invstd.data_ptr(), g, b,
+                                     res.data_ptr() if res is not None else None, y.data_ptr(), M, Cc, Cc, int(relu), _st()),
+            "bevf_bn_apply_f32")
     if bn.track_running_stats and bn.running_mean is not None:           # torch: momentum 0.1, unbiased running var
         mom = 0.1 if bn.momentum is None else bn.momentum
         nbt = bn.num_batches_tracked
@@ -321,6 +324,31 @@ class ConvBNLayer:
         y, self.bns = bn_train_forward(xraw, self.bn, self.M, self.cout, res=res, relu=self.relu)
         self.has_res = res is not None
         return y, Ho, Wo
+
+    def forward_groupmax(self, x, B: int, P: int):
+        """conv (1x1 over B*P rows) -> train-mode BN -> ReLU -> max over the P rows of each group, without writing the
+        activation: the max / argmax kernel evaluates relu(bn(.)) from the raw rows with bn_apply's own fma.  Returns
+        (gmax [B*cout], idx int32 [B*cout]); pair with backward_from_groupmax."""
+        assert self.bn is not None and self.relu and self.k == 1
+        w4 = self.conv.weight.detach()
+        if w4.dim() == 3:
+            w4 = w4.unsqueeze(-1)
+        w_ohwi = w4.permute(0, 2, 3, 1).contiguous().view(-1)
+        bias = self.conv.bias.detach() if self.conv.bias is not None else None
+        M = B * P
+        self.x, self.N, self.H, self.W, self.M, self.has_res = x, M, 1, 1, M, False
+        xraw, _, _ = conv_raw(x, w_ohwi, bias, M, 1, 1, self.cin, self.cout, 1, 1, 0)
+        _, self.bns = bn_train_forward(xraw, self.bn, M, self.cout, relu=True, apply=False)
+        dev = x.device
+        g = _new(B * self.cout, dev)
+        idx = torch.empty(B * self.cout, dtype=torch.int32, device=dev)
+        work = torch.empty(_lib().bevf_group_max_idx_work_bytes(B, P, self.cout), dtype=torch.uint8, device=dev)
+        gam = self.bn.weight.data_ptr() if self.bn.weight is not None else None
+        bet = self.bn.bias.data_ptr() if self.bn.bias is not None else None
+        _ck(_lib().bevf_bn_relu_group_max_idx_f32(xraw.data_ptr(), self.bns.mean.data_ptr(), self.bns.invstd.data_ptr(), gam, bet,
+                                                  g.data_ptr(), idx.data_ptr(), work.data_ptr(), B, P, self.cout, _st()),
+            "bevf_bn_relu_group_max_idx_f32")
+        return g, idx
 
     def backward(self, dy, sink: GradSink, need_dx=True, add=None):
         """dy: gradient of the layer output (modified in place).  Returns (dx or None, d_res or None); `add` is summed
@@ -511,16 +539,13 @@ class DetectorTape:
         assert use_bn, "training path expects use_bn=True PointNet"
         a, self.pn_bn0 = bn_train_forward(raw, enc.bn1, M, c0, relu=True)
         self.pn_layers = []
-        for i in range(2, 6):
+        for i in range(2, 5):
             lyr = ConvBNLayer(getattr(enc, f"conv{i}"), getattr(enc, f"bn{i}"), True)
             a, _, _ = lyr.forward(a, M, 1, 1)
             self.pn_layers.append(lyr)
-        feat = lyr.cout
-        g = _new(B * feat, dev)
-        self.pn_idx = torch.empty(B * feat, dtype=torch.int32, device=dev)
-        gwork = torch.empty(_lib().bevf_group_max_idx_work_bytes(B, Np, feat), dtype=torch.uint8, device=dev)
-        _ck(_lib().bevf_group_max_idx_f32(a.data_ptr(), g.data_ptr(), self.pn_idx.data_ptr(), gwork.data_ptr(), B, Np, feat,
-                                          _st()), "bevf_group_max_idx_f32")
+        lyr = ConvBNLayer(enc.conv5, enc.bn5, True)               # last layer: BN + ReLU + max over points, fused
+        g, self.pn_idx = lyr.forward_groupmax(a, B, Np)
+        self.pn_layers.append(lyr)
         self.pn_g = g
         return g
 

@@ -338,6 +338,10 @@ int bevf_cam_mean_bwd_f32(const float* dy, float* dx, int B, int ncam, int P, in
 size_t bevf_group_max_idx_work_bytes(int G, int P, int C);
 int bevf_group_max_idx_f32(const float* x, float* y, int32_t* idx, void* work, int G, int P, int C, void* stream);
 int bevf_group_max_bwd_f32(const float* dy, const int32_t* idx, float* dx, int G, int P, int C, void* stream); /* dx zero-filled */
+/* Same max / argmax (work: bevf_group_max_idx_work_bytes) over relu(batchnorm(x)) evaluated on the fly from the raw
+ * rows x with bn_apply's own fma: the training forward of PointNet's last layer writes no activation.            */
+int bevf_bn_relu_group_max_idx_f32(const float* x, const float* mean, const float* invstd, const float* gamma,
+                                   const float* beta, float* y, int32_t* idx, void* work, int G, int P, int C, void* stream);
 /* Backward of max-over-rows( relu( batchnorm(x) ) ) without the dense intermediate gradient (PointNet's last layer,
  * ref src/encoders.py:296-299): dg / gmax / idx [B][C] = gradient, value and argmax row of the max; writes dgamma,
  * dbeta, dx [B*P][cs]; dgm [B][C] scratch.                                                                        */
