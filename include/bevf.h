@@ -46,7 +46,8 @@ const char* bevf_last_error(void);
  * With `colmax` set the output is not stored; instead the per-group column maximum
  * (torch.max(x, 2)[0], ref src/encoders.py:298) is accumulated with integer atomics on the
  * non-negative post-ReLU bit patterns (order-independent, hence deterministic).
- * Requires Cin % 32 == 0, x_cs % 4 == 0, 16-byte aligned x / w.
+ * Requires Cin % 32 == 0, x_cs % 4 == 0, 16-byte aligned x / w, and x / w below 2 GiB each (32-bit buffer
+ * offsets; callers chunk larger batches over images).
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
   const float* x;      /* [N][H][W][x_cs], first Cin channels of each pixel are read        */
@@ -61,7 +62,8 @@ typedef struct {
   int32_t KH, KW, stride, pad;
   int32_t relu;            /* 0: none, 1: ReLU                                               */
   int32_t rows_per_group;  /* colmax grouping (points per batch element)                     */
-  int32_t tile;            /* 0: auto; else forces a tile variant (bench/tests)              */
+  int32_t tile;            /* 0: auto (cost model); 1 128x128, 2 256x64, 3 128x64, 4 64x64, 5-7 hybrid
+                              big + 64x64 tail of 1 / 2 / 3 -- forced variants for bench / tests     */
 } bevf_conv_desc;
 int bevf_conv2d_nhwc_f32(const bevf_conv_desc* d, void* stream);
 
