@@ -1,32 +1,39 @@
 #!/usr/bin/env python3
 """bench.py -- BEV frames/sec of the detector forward on MI355X (BASELINE.json's metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--config 2|3|1]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--config 2|3|1|5] [--mode infer|train]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step = one forward of `FlexibleMultiModal3DDetector` over a batch of B synthetic frames
 (config 2 of BASELINE.json by default: 6 x 900x1600 cameras + 35k-point LiDAR, 128x128 BEV,
 fp32, random-init weights), inputs resident in HBM, head tensors as outputs.  Frames shard
 over ranks as independent replicas (inference has no collective) -> weak scaling.
-Rank 0 prints ONE JSON line with the whole-job frames/s, the live roofline of the dominant
-kernel (conv_igemm_f32, HIP events on the launch stream inside the timed region) and the CPU
-baseline (the oracle on the host cores, N=1 only).
+
+`--gpus N` with N > 1 and no torchrun environment: this process launches N ranks itself
+(`python -m torch.distributed.run ... bench.py --gpus N ...`, one per GPU, rendezvous on 127.0.0.1)
+BEFORE it touches the GPU, forwards their output and exits with their code.  Every rank
+checks that the world it joined has exactly N ranks and fails otherwise.
+
+Rank 0 prints ONE JSON line: the whole-job frames/s of the headline configuration, the live
+roofline of its dominant kernel (conv_igemm_f32, HIP events on the launch stream inside the
+timed region), the CPU baseline (the oracle on the host cores, N=1 only) and, under
+`extra.configs`, short legs of the other BASELINE configs (3: bf16 full fusion, 5: bf16
+bandwidth-stress, 4: the training step with its gradient all-reduce), each with its own
+live roofline.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from bevfusion_multimodal_3d_object_detection_amd import engine, fusion, replicas, synth   # noqa: E402
-
 CONFIGS = {
-    # BASELINE.json configs[0..2]; (modality, cams, H, W, points, radars, bev)
+    # BASELINE.json configs[0..4]; (modality, cams, H, W, points, radars, bev)
     1: dict(name="camera_only 6x448x800, BEV 128x128 (reference-runnable sanity shape)",
             modality="camera_only", cams=6, h=448, w=800, points=0, radars=0, bev=128),
     2: dict(name="camera+LiDAR, 6x900x1600 images + 35k-point sweep, BEV 128x128",
@@ -42,31 +49,96 @@ CONFIGS = {
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+PMC_PROFILE_ROUNDS = ("r02", "r01")
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=None,
+                    help="frames per step per GPU (default 8; 2 for config 5, whose B=8 activations pass the 2 GiB buffer limit)")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="train = BASELINE config 4: fwd + targets + loss + bwd + grad all-reduce + clip + AdamW")
+    ap.add_argument("--dtype", choices=["fp32", "bf16", "f32x3"], default="fp32",
+                    help="fp32 (default): exact fp32 MFMA.  bf16 = BASELINE configs 3/5: bf16 storage, fp32 accumulate.  "
+                         "f32x3: fp32 storage, convolutions through an exact 3-way bf16 split on the bf16 MFMA "
+                         "(fp32-level error, not bit-identical to fp32; opt-in, never the headline)")
+    ap.add_argument("--graph", action="store_true", help="replay the inference forward as one hipGraph (small batches)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true", help="skip the per-launch HIP-event brackets")
+    ap.add_argument("--extras", choices=["auto", "all", "none"], default="auto",
+                    help="extra.configs legs after the headline: auto = configs 3 (bf16), 5 (bf16) and 4 (train) at N=1, "
+                         "the data-parallel training leg only at N>1 (it is the one with a collective); none = headline only")
+    ap.add_argument("--extra-steps", type=int, default=4)
+    return ap.parse_args(argv)
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks_if_needed(args, argv) -> None:
+    """`--gpus N` without a torchrun environment: start N ranks as children of this process (which has made no GPU
+    call and never will) and exit with their code.  A torchrun environment of a different size is an error."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if int(env_world) != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher made WORLD_SIZE={env_world} ranks; "
+                             "pass --gpus equal to --nproc-per-node")
+        return
+    if args.gpus <= 1:
+        return
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
 def build_model(cfg, seed=0):
+    from bevfusion_multimodal_3d_object_detection_amd import fusion, synth
     model = fusion.create_detector(cfg["modality"], "bev", "centernet", bev_h=cfg["bev"], bev_w=cfg["bev"])
     synth.fill_state_dict_(model, seed)
     return model.eval()
 
 
-def make_inputs(cfg, batch, seed, dev):
-    imgs, pts, radars = synth.frame_inputs(batch, cfg["cams"], cfg["h"], cfg["w"], cfg["points"], 4,
-                                           cfg["radars"], 125, 7, seed=seed)
-    return (imgs.to(dev) if imgs is not None else None, pts.to(dev) if pts is not None else None,
-            [r.to(dev) for r in radars] if radars else None)
+class InputCache:
+    """Synthetic frames regenerated from (seed, element index) on the host; the image block (the expensive part:
+    207 M normals at B=8) is shared by the legs that use the same image shape."""
+
+    def __init__(self, dev):
+        self.dev, self.imgs = dev, {}
+
+    def get(self, cfg, batch, seed):
+        from bevfusion_multimodal_3d_object_detection_amd import synth
+        key = (batch, cfg["cams"], cfg["h"], cfg["w"], seed)
+        if cfg["cams"] and key not in self.imgs:
+            self.imgs[key] = synth.frame_inputs(batch, cfg["cams"], cfg["h"], cfg["w"], 0, 4, 0, 125, 7, seed=seed)[0].to(self.dev)
+        _, pts, radars = synth.frame_inputs(batch, 0, 0, 0, cfg["points"], 4, cfg["radars"], 125, 7, seed=seed)
+        return (self.imgs[key] if cfg["cams"] else None, pts.to(self.dev) if pts is not None else None,
+                [r.to(self.dev) for r in radars] if radars else None)
+
+    def drop(self):
+        self.imgs.clear()
 
 
 def pmc_traffic(config: int, batch: int):
     """HBM-side bytes per conv launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, see
-    tools/pmc_summary.py); only valid for the configuration the profile was taken on."""
-    path = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_config{config}_b{batch}.json")
-    if not os.path.exists(path):
-        return None
-    d = json.load(open(path))
-    n = sum(v["launches"] for k, v in d.items() if k.startswith("conv_igemm"))
-    tot = sum(v["launches"] * v["hbm_bytes_per_launch"] for k, v in d.items() if k.startswith("conv_igemm"))
-    return (tot / n, os.path.relpath(path, ROOT)) if n else None
+    tools/pmc_summary.py); only valid for the configuration the profile was taken on.  bench.py cannot read PMC
+    counters itself (they need rocprofv3 around the process), so the figure is labelled with its source."""
+    for rnd in PMC_PROFILE_ROUNDS:
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_config{config}_b{batch}.json")
+        if os.path.exists(path):
+            d = json.load(open(path))
+            n = sum(v["launches"] for k, v in d.items() if k.startswith("conv_igemm"))
+            tot = sum(v["launches"] * v["hbm_bytes_per_launch"] for k, v in d.items() if k.startswith("conv_igemm"))
+            if n:
+                return tot / n, "committed profile: " + os.path.relpath(path, ROOT)
+    return None
 
 
 def host_cores() -> int:
@@ -84,6 +156,8 @@ def host_cores() -> int:
 
 def cpu_baseline(cfg, state_dict, budget_s=12.0):
     """The oracle (CPU restatement, oracle/ref_model.py) on the host cores, B=1, same synthetic frame."""
+    import torch
+    from bevfusion_multimodal_3d_object_detection_amd import synth
     from oracle import ref_model
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -103,65 +177,33 @@ def cpu_baseline(cfg, state_dict, budget_s=12.0):
                 sample=f"{n} frames at B=1 after 1 warm-up, oracle/ref_model.py (PyTorch-CPU fp32), same config")
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=None,
-                    help="frames per step per GPU (default 8; 2 for config 5, whose B=8 activations pass the 2 GiB buffer limit)")
-    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
-    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
-                    help="train = BASELINE config 4: fwd + targets + loss + bwd + grad all-reduce + clip + AdamW")
-    ap.add_argument("--dtype", choices=["fp32", "bf16", "f32x3"], default="fp32",
-                    help="fp32 (default): exact fp32 MFMA.  bf16 = BASELINE configs 3/5: bf16 storage, fp32 accumulate.  "
-                         "f32x3: fp32 storage, convolutions through an exact 3-way bf16 split on the bf16 MFMA "
-                         "(fp32-level error, not bit-identical to fp32; opt-in, never the headline)")
-    ap.add_argument("--graph", action="store_true", help="replay the inference forward as one hipGraph (small batches)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-timer", action="store_true", help="skip the per-launch HIP-event brackets")
-    args = ap.parse_args()
-
-    rank, local_rank, world = replicas.rank_world()
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    # one process per GPU.  BEVF_DIST_BACKEND=gloo + fewer GPUs than ranks is a control-flow rehearsal only
-    # (ranks then share a device); the driver's runs use the default: RCCL, one GPU per rank.
-    backend = os.environ.get("BEVF_DIST_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    dist = replicas.init(backend, dev)             # RCCL; only for the barrier and the MAX of the elapsed time
-    if args.mode == "train":
-        args.config = 4
-    cfg = CONFIGS[args.config]
-    if args.batch is None:
-        args.batch = 2 if args.config == 5 else 8
-
+def run_leg(config, dtype, mode, batch, steps, warmup, ctx, graph=False, kernel_timer=True, keep_state=False):
+    """One timed leg: W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both
+    sides, MAX over ranks.  Returns the leg's record (value = whole-job frames/s) and, if asked, the state dict."""
+    import torch
+    from bevfusion_multimodal_3d_object_detection_amd import engine, replicas, synth
+    dev, dist, rank, world = ctx["dev"], ctx["dist"], ctx["rank"], ctx["world"]
+    cfg = CONFIGS[config]
     model_cpu = build_model(cfg)
-    state = {k: v.clone() for k, v in model_cpu.state_dict().items()}
+    state = {k: v.clone() for k, v in model_cpu.state_dict().items()} if keep_state else None
     model = model_cpu.to(dev)
-    if args.dtype == "f32x3":
-        if args.mode == "train":
-            raise SystemExit("training runs in exact fp32")
-        engine.set_conv_mode("f32x3")
-    if args.dtype == "bf16":
-        if args.mode == "train":
-            raise SystemExit("training runs in fp32 (the reference has no mixed precision, SURVEY.md 5)")
+    engine.set_conv_mode("f32x3" if dtype == "f32x3" else "f32")
+    if dtype == "bf16":
         model = model.bfloat16()
-    inputs = make_inputs(cfg, args.batch, replicas.frame_seed(0x5EED, args.config, rank), dev)
+    seed = replicas.frame_seed(0x5EED, config if mode == "train" else 2, rank)     # inference legs share config 2's images
+    inputs = ctx["inputs"].get(cfg, batch, seed)
 
-    if args.mode == "train":
+    if mode == "train":
         from bevfusion_multimodal_3d_object_detection_amd import centernet_target as ct
         from bevfusion_multimodal_3d_object_detection_amd import training
         model.train()
-        boxes, labels = synth.gt_boxes(args.batch, 20, seed=replicas.frame_seed(0x5EED, args.config, rank))
+        boxes, labels = synth.gt_boxes(batch, 20, seed=seed)
         gt = {"gt_boxes": boxes.to(dev), "gt_labels": labels.to(dev)}
         crit = ct.CenterNetLoss()
         # ref train_detect.py:725-741 (AdamW lr 1e-4 wd 0.01) and :431 (clip_grad_norm_ 10), clip folded into the update
         opt = training.FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.01, max_grad_norm=10.0)
-
-        if dist is not None:          # DP: gradient all-reduce (RCCL) issued from inside the backward, overlapped with it
-            training.set_grad_reducer(replicas.GradReducer(dist))
+        reducer = replicas.GradReducer(dist) if dist is not None else None
+        training.set_grad_reducer(reducer)     # DP: gradient all-reduce (RCCL) issued from inside the backward, overlapped
 
         def step():
             pred = model(*inputs)
@@ -171,9 +213,9 @@ def main():
             losses["total_loss"].backward()
             opt.step()
             return {k: v.detach() for k, v in losses.items()}
-    elif args.graph:
+    elif graph:
         graphed = model.make_graphed(*inputs)
-        args.no_kernel_timer = True                     # per-launch event brackets cannot live inside a captured graph
+        kernel_timer = False                            # per-launch event brackets cannot live inside a captured graph
 
         def step():
             return graphed(*inputs)
@@ -181,91 +223,190 @@ def main():
         def step():
             return model(*inputs)
 
-    for _ in range(max(args.warmup, 1)):
-        out = step()
-    torch.cuda.synchronize()
-    assert all(torch.isfinite(v).all() for v in out.values()), "non-finite head output"
+    try:
+        for _ in range(max(warmup, 1)):
+            out = step()
+        torch.cuda.synchronize()
+        assert all(torch.isfinite(v).all() for v in out.values()), "non-finite head output"
 
-    # Inference: the per-launch HIP-event brackets (37 launches a step) ride inside the timed region.  Training issues
-    # ~700 launches a step and the brackets' host cost would distort `value`, so its roofline is taken over two extra,
-    # untimed steps right after the timed region.
-    timer = None if args.no_kernel_timer else engine.KernelTimer()
-    timer_in_region = timer is not None and args.mode == "infer"
-    engine.set_timer(timer if timer_in_region else None)
+        # Inference: the per-launch HIP-event brackets (37 launches a step) ride inside the timed region.  Training
+        # issues ~700 launches a step and the brackets' host cost would distort `value`, so its roofline is taken
+        # over two extra, untimed steps right after the timed region.
+        timer = engine.KernelTimer() if kernel_timer else None
+        timer_in_region = timer is not None and mode == "infer"
+        engine.set_timer(timer if timer_in_region else None)
+        replicas.barrier(dist)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        torch.cuda.synchronize()
+        replicas.barrier(dist)
+        elapsed = time.perf_counter() - t0
+        engine.set_timer(None)
+        elapsed = replicas.max_over_ranks(elapsed, dist, dev)
+        timer_steps, timer_elapsed = steps, elapsed
+        if timer is not None and not timer_in_region:
+            engine.set_timer(timer)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            timer_steps, timer_elapsed = 2, time.perf_counter() - t1
+            engine.set_timer(None)
+    finally:
+        engine.set_timer(None)
+        engine.set_conv_mode("f32")
+        if mode == "train":
+            training.set_grad_reducer(None)
+
+    rec = {"workload": cfg["name"], "dtype": dtype, "batch_per_gpu": batch, "steps": steps, "warmup": warmup,
+           "value": replicas.aggregate_fps(batch * steps, world, elapsed), "unit": "frames/s",
+           "ms_per_step": 1e3 * elapsed / steps,
+           "mode": "inference forward -> 5 head tensors" if mode == "infer"
+           else "training step: fwd (train-mode BN) + targets + loss + bwd + grad all-reduce + clip + AdamW"}
+    if mode == "train" and dist is not None:
+        rec["grad_allreduce"] = {"collectives_per_step": reducer.collectives / max(1, warmup + steps + (2 if timer else 0)),
+                                 "backend": dist.get_backend(), "ranks": dist.get_world_size()}
+    if timer is not None:
+        tot = timer.totals()
+        conv = tot.get("conv_igemm_f32")
+        if conv and mode == "train":                          # forward + data-gradient + weight-gradient GEMMs
+            for extra in ("conv_dgrad_f32", "conv_wgrad_f32"):
+                e = tot.get(extra)
+                if e:
+                    conv = {k: conv[k] + e[k] for k in conv}
+        if conv:
+            ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
+            # f32x3 spends six bf16 MFMA products per algorithmic multiply-add: its ceiling is a sixth of the bf16 peak
+            peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "f32x3": PEAK_BF16_MFMA_TFLOPS / 6.0}[dtype]
+            kname = {"fp32": "conv_igemm_f32", "bf16": "conv_igemm_bf16", "f32x3": "conv_split_f32x3"}[dtype]
+            rec["roofline"] = {"kernel": kname if mode == "infer" else "conv_igemm_f32+conv_wgrad_f32",
+                               "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                               "traffic": None, "traffic_source": None,
+                               "launches_per_step": conv["launches"] / timer_steps,
+                               "avg_launch_ms": conv["ms"] / conv["launches"],
+                               "gflop_per_step": conv["flops"] / timer_steps / 1e9,
+                               "share_of_step": conv["ms"] / (1e3 * timer_elapsed),
+                               "measured_over": "the timed region" if timer_in_region else "2 untimed steps after the timed region"}
+            tr = pmc_traffic(config, batch) if dtype == "fp32" and mode == "infer" else None
+            if tr is not None:
+                rec["roofline"]["traffic"], rec["roofline"]["traffic_source"] = tr
+        pool = tot.get("bev_pool")
+        if pool:
+            gbs = pool["bytes"] / (pool["ms"] * 1e-3) / 1e9
+            rec["roofline_bev_pool"] = {"kernel": "cam_mean+bilinear_nhwc", "bound": "hbm", "achieved": gbs,
+                                        "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                                        "traffic": None, "mb_per_step": pool["bytes"] / timer_steps / 1e6}
+        stem = tot.get("stem_conv7x7_f32")
+        if stem:
+            rec["stem_tflops"] = stem["flops"] / (stem["ms"] * 1e-3) / 1e12
+    del model, inputs, out
+    torch.cuda.empty_cache()
+    return rec, state
+
+
+def stub_main(args):
+    """BEVF_BENCH_STUB=1: the launcher / rank / barrier / MAX-over-ranks control flow with a CPU stand-in for the step
+    (CPU-only rehearsal of `--gpus N`, tests/test_multiproc_gloo.py); prints the same JSON skeleton, no measurements."""
+    import torch
+    from bevfusion_multimodal_3d_object_detection_amd import replicas
+    rank, _, world = replicas.rank_world()
+    dist = replicas.init(os.environ.get("BEVF_DIST_BACKEND", "gloo"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but {world} rank(s) are running")
+    x = torch.ones(64, 64)
     replicas.barrier(dist)
-    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
+        x = (x @ x).clamp_(max=1.0)
     replicas.barrier(dist)
-    elapsed = time.perf_counter() - t0
-    engine.set_timer(None)
-    elapsed = replicas.max_over_ranks(elapsed, dist, dev)
-    timer_steps, timer_elapsed = args.steps, elapsed
-    if timer is not None and not timer_in_region:
-        engine.set_timer(timer)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize()
-        timer_steps, timer_elapsed = 2, time.perf_counter() - t1
-        engine.set_timer(None)
+    elapsed = replicas.max_over_ranks(time.perf_counter() - t0, dist, torch.device("cpu"))
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": replicas.aggregate_fps(args.steps, world, elapsed), "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "stub": True,
+                          "dist": {"backend": dist.get_backend() if dist else None,
+                                   "ranks": dist.get_world_size() if dist else 1}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    launch_ranks_if_needed(args, argv)              # may not return; nothing above this line touches the GPU
+    if os.environ.get("BEVF_BENCH_STUB") == "1":
+        return stub_main(args)
+
+    import torch
+    from bevfusion_multimodal_3d_object_detection_amd import replicas
+    rank, local_rank, world = replicas.rank_world()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but {world} rank(s) are running")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    # one process per GPU.  BEVF_DIST_BACKEND=gloo + fewer GPUs than ranks is a control-flow rehearsal only
+    # (ranks then share a device); the driver's runs use the default: RCCL, one GPU per rank.
+    backend = os.environ.get("BEVF_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    dist = replicas.init(backend, dev)             # RCCL; inference: only the barrier and the MAX of the elapsed time
+    if dist is not None and dist.get_world_size() != args.gpus:
+        raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
+    if args.mode == "train":
+        args.config = 4
+        if args.dtype != "fp32":
+            raise SystemExit("training runs in exact fp32 (the reference has no mixed precision, SURVEY.md 5)")
+    cfg = CONFIGS[args.config]
+    if args.batch is None:
+        args.batch = 2 if args.config == 5 else 8
+    ctx = dict(dev=dev, dist=dist, rank=rank, world=world, inputs=InputCache(dev))
+
+    head, state = run_leg(args.config, args.dtype, args.mode, args.batch, args.steps, args.warmup, ctx,
+                          graph=args.graph, kernel_timer=not args.no_kernel_timer, keep_state=True)
+
+    extras = []
+    if args.extras != "none" and not args.graph:
+        plan = [(3, "bf16", "infer", 8), (5, "bf16", "infer", 2), (4, "fp32", "train", 8)]
+        if world > 1 and args.extras == "auto":
+            plan = [(4, "fp32", "train", 8)]
+        plan = [p for p in plan if (p[0], p[1], p[2]) != (args.config, args.dtype, args.mode)]
+        for config, dtype, mode, batch in plan:
+            if mode == "train":
+                ctx["inputs"].drop()
+            try:
+                rec, _ = run_leg(config, dtype, mode, batch, args.extra_steps, 2, ctx)
+            except Exception as e:                               # a failed extra never takes the headline with it
+                rec = {"workload": CONFIGS[config]["name"], "dtype": dtype, "error": f"{type(e).__name__}: {e}"[:300]}
+            extras.append(rec)
 
     if rank == 0:
         line = {
             "metric": f"BEV frames/sec (6-cam+LiDAR, {cfg['bev']}x{cfg['bev']} BEV)",
-            "value": replicas.aggregate_fps(args.batch * args.steps, world, elapsed), "unit": "frames/s",
+            "value": head["value"], "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": cfg["name"], "batch_per_gpu": args.batch,
                        "parallelism": f"replicas x{world}" if args.mode == "infer" else f"dp{world}",
                        "weights": "random-init (synthetic, seeded)", "launch": "hipGraph replay" if args.graph else "eager",
-                       "mode": "inference forward -> 5 head tensors" if args.mode == "infer"
-                       else "training step: fwd (train-mode BN) + targets + loss + bwd + grad all-reduce + clip + AdamW"},
+                       "mode": head["mode"]},
+            # ranks of the process group the barrier / MAX (and, in training legs, the gradient all-reduce) ran on
+            "rccl_ranks": dist.get_world_size() if (dist is not None and dist.get_backend() == "nccl") else (1 if dist is None else 0),
+            "dist_backend": dist.get_backend() if dist is not None else None,
         }
         if args.mode == "train":
             line["metric"] = "training frames/sec (camera+LiDAR, per-GPU batch 8)"
-        if timer is not None:
-            tot = timer.totals()
-            conv = tot.get("conv_igemm_f32")
-            if conv and args.mode == "train":                          # forward + data-gradient + weight-gradient GEMMs
-                for extra in ("conv_dgrad_f32", "conv_wgrad_f32"):
-                    e = tot.get(extra)
-                    if e:
-                        conv = {k: conv[k] + e[k] for k in conv}
-            if conv:
-                ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
-                # f32x3 spends six bf16 MFMA products per algorithmic multiply-add: its ceiling is a sixth of the bf16 peak
-                peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS,
-                        "f32x3": PEAK_BF16_MFMA_TFLOPS / 6.0}[args.dtype]
-                kname = {"fp32": "conv_igemm_f32", "bf16": "conv_igemm_bf16", "f32x3": "conv_split_f32x3"}[args.dtype]
-                line["roofline"] = {"kernel": kname if args.mode == "infer" else "conv_igemm_f32+conv_wgrad_f32",
-                                    "bound": "mfma", "achieved": ach,
-                                    "traffic_source": None,
-                                    "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                                    "traffic": None, "launches_per_step": conv["launches"] / timer_steps,
-                                    "avg_launch_ms": conv["ms"] / conv["launches"],
-                                    "gflop_per_step": conv["flops"] / timer_steps / 1e9,
-                                    "share_of_step": conv["ms"] / (1e3 * timer_elapsed),
-                                    "measured_over": "the timed region" if timer_in_region else "2 untimed steps after the timed region"}
-                tr = pmc_traffic(args.config, args.batch) if args.dtype == "fp32" and args.mode == "infer" else None
-                if tr is not None:
-                    line["roofline"]["traffic"], line["roofline"]["traffic_source"] = tr
-            pool = tot.get("bev_pool")
-            if pool:
-                gbs = pool["bytes"] / (pool["ms"] * 1e-3) / 1e9
-                line["roofline_bev_pool"] = {"kernel": "cam_mean+bilinear_nhwc", "bound": "hbm", "achieved": gbs,
-                                             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                                             "traffic": None, "mb_per_step": pool["bytes"] / timer_steps / 1e6}
-            stem = tot.get("stem_conv7x7_f32")
-            if stem:
-                line["stem_tflops"] = stem["flops"] / (stem["ms"] * 1e-3) / 1e12
+        for k in ("roofline", "roofline_bev_pool", "stem_tflops", "grad_allreduce"):
+            if k in head:
+                line[k] = head[k]
         if world == 1 and not args.no_cpu_baseline and args.mode == "infer":
             line["cpu_baseline"] = cpu_baseline(cfg, state)
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+        if extras:
+            line["extra"] = {"configs": extras}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

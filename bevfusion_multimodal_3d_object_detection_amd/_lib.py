@@ -42,8 +42,8 @@ class HeadDesc(C.Structure):
 
 class DecodeDesc(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("heat", "offset", "size", "rot", "vel", "boxes", "scores", "labels",
-                                          "velocities", "count", "work")] + \
-               [(n, C.c_int32) for n in ("B", "C", "H", "W", "K", "true_labels")] + \
+                                          "velocities", "count", "work", "pool_ind")] + \
+               [(n, C.c_int32) for n in ("B", "C", "H", "W", "K", "true_labels", "raw_scores")] + \
                [(n, C.c_float) for n in ("thresh", "voxel", "x_min", "y_min")]
 
 
@@ -380,7 +380,7 @@ def fill(y: torch.Tensor, v: float):
 
 
 def centernet_decode(pred: dict, K: int, thresh: float, voxel: float, x_min: float, y_min: float,
-                     true_labels: bool = False):
+                     true_labels: bool = False, raw_scores: bool = False, pool_ind: Optional[torch.Tensor] = None):
     heat = pred["heatmap"]
     B, Cn, H, W = heat.shape
     dev = heat.device
@@ -395,7 +395,8 @@ def centernet_decode(pred: dict, K: int, thresh: float, voxel: float, x_min: flo
     work = torch.empty(lib().bevf_centernet_decode_work_bytes(B, Cn, H, W, K), dtype=torch.uint8, device=dev)
     d = DecodeDesc(_pc(heat), _pc(pred["offset"]), _pc(pred["size"]), _pc(pred["rot"]), _pc(pred["vel"]),
                    _p(boxes), _p(scores), _p(labels, torch.int64), _p(vels), _p(count, torch.int32),
-                   _p(work, torch.uint8), B, Cn, H, W, K, int(true_labels), thresh, voxel, x_min, y_min)
+                   _p(work, torch.uint8), _p(pool_ind, torch.int64), B, Cn, H, W, K, int(true_labels),
+                   int(raw_scores), thresh, voxel, x_min, y_min)
     _check(lib().bevf_centernet_decode_f32(C.byref(d), _stream()), "bevf_centernet_decode_f32")
     return boxes, scores, labels, vels, count
 
@@ -466,8 +467,12 @@ def centernet_loss(pred: dict, tgt: dict, weights) -> torch.Tensor:
 
 
 def centernet_decode_raw(pred: dict, K: int):
-    """Top-K bookkeeping only: voxel 1, origin 0, zero offsets -> boxes[...,0:2] are the integer (x, y) cells."""
-    return centernet_decode(pred, K, -1.0, 1.0, 0.0, 0.0, False)
+    """Top-K bookkeeping only (no keep mask): voxel 1, origin 0, zero offsets -> boxes[...,0:2] are the integer
+    (x, y) cells; also returns each winner's position in the (C,K) pool."""
+    heat = pred["heatmap"]
+    pool_ind = torch.empty(heat.shape[0], K, dtype=torch.int64, device=heat.device)
+    boxes, scores, labels, _, _ = centernet_decode(pred, K, -1.0, 1.0, 0.0, 0.0, False, True, pool_ind)
+    return boxes, scores, labels, pool_ind
 
 
 def voxelize(points: torch.Tensor, pc_range, voxel_size, max_points: int, max_voxels: int):

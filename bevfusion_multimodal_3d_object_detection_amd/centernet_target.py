@@ -57,6 +57,34 @@ def _nms(heat: torch.Tensor, kernel: int = 3) -> torch.Tensor:
     return out
 
 
+def gaussian_2d(shape: Tuple[int, int], sigma: float = 1.0):
+    """ref :118-125 -- (m,n) gaussian window exp(-(x^2+y^2)/(2 sigma^2)) centred on the middle element, values below
+    eps*max flushed to 0.  Host numpy helper kept for API parity (`prepare_centernet_targets` evaluates the same
+    window inside its kernel)."""
+    import numpy as np
+    half_m, half_n = (shape[0] - 1.) / 2., (shape[1] - 1.) / 2.
+    y, x = np.ogrid[-half_m:half_m + 1, -half_n:half_n + 1]
+    g = np.exp(-(x * x + y * y) / (2 * sigma * sigma))
+    g[g < np.finfo(g.dtype).eps * g.max()] = 0
+    return g
+
+
+def draw_gaussian(heatmap, center: Tuple[int, int], radius: float, k: float = 1.0):
+    """ref :152-168 -- element-wise max of `heatmap` (H,W numpy array, modified in place) with a (2r+1)^2 gaussian of
+    sigma (2r+1)/6 centred on `center` = (x, y), clipped at the borders.  Host helper for API parity."""
+    import numpy as np
+    diameter = 2 * radius + 1
+    g = gaussian_2d((diameter, diameter), sigma=diameter / 6)
+    x, y = int(center[0]), int(center[1])
+    H, W = heatmap.shape[0:2]
+    left, right = min(x, radius), min(W - x, radius + 1)
+    top, bottom = min(y, radius), min(H - y, radius + 1)
+    dst = heatmap[y - top:y + bottom, x - left:x + right]
+    src = g[radius - top:radius + bottom, radius - left:radius + right]
+    if min(src.shape) > 0 and min(dst.shape) > 0:
+        np.maximum(dst, src * k, out=dst)
+
+
 def gaussian_radius(det_size: Tuple[float, float], min_overlap: float = 0.7) -> float:
     """ref :128-150 (host helper kept for API parity; the device kernel evaluates the same expression)."""
     import numpy as np
@@ -134,3 +162,14 @@ def _topk(scores: torch.Tensor, K: int = 100):
     """ref :424-452 (see fusion_detection._topk)."""
     from .fusion_detection import _topk as impl
     return impl(scores, K)
+
+
+class DetectionLoss(nn.Module):
+    """ref :13-116 -- the loss of the MLP-head path (`cls`/`box` predictions), imported by src/train_detect.py:24-29
+    but never used by the bev + centernet path (out of scope as compute).  Importable name that
+    raises on construction."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError("DetectionLoss (ref src/centernet_target.py:13-116) belongs to the MLP detection "
+                                  "head, which is outside the MI355X bev+centernet hot path; use CenterNetLoss")

@@ -40,7 +40,8 @@ struct DecArgs {
   float* boxes; float* scores; long long* labels; float* velocities; int* count;
   uint32_t* keys;                 // [B*C][H*W] masked, order-preserving score bits
   unsigned long long* cls_top;    // [B*C][K]   composite keys of the per-class winners
-  int B, C, H, W, K, Kp, poolp, true_labels;
+  long long* pool_ind;
+  int B, C, H, W, K, Kp, poolp, true_labels, raw_scores;
   float thresh, voxel, x_min, y_min;
 };
 
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void decode_class_topk(const DecArgs a) {
     const int y = i / a.W, x = i - y * a.W;
     const float v = hp[i];
     float m = v;
-    for (int dy = -1; dy <= 1; ++dy) {
+    if (!a.raw_scores) for (int dy = -1; dy <= 1; ++dy) {
       const int yy = y + dy;
       if ((unsigned)yy >= (unsigned)a.H) continue;
       for (int dx = -1; dx <= 1; ++dx) {
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(256) void decode_frame(const DecArgs a) {
     const size_t o = (size_t)b * a.K + k;
     a.scores[o] = score;
     a.labels[o] = label;
+    if (a.pool_ind) a.pool_ind[o] = valid ? j : 0;
     for (int q = 0; q < 7; ++q) a.boxes[o * 7 + q] = box[q];
     a.velocities[o * 2] = v2[0];
     a.velocities[o * 2 + 1] = v2[1];
@@ -203,7 +205,8 @@ extern "C" int bevf_centernet_decode_f32(const bevf_decode_desc* d, void* stream
   a.heat = d->heat; a.offset = d->offset; a.size = d->size; a.rot = d->rot; a.vel = d->vel;
   a.boxes = d->boxes; a.scores = d->scores; a.labels = (long long*)d->labels; a.velocities = d->velocities;
   a.count = d->count;
-  a.B = d->B; a.C = d->C; a.H = d->H; a.W = d->W; a.K = d->K; a.true_labels = d->true_labels;
+  a.B = d->B; a.C = d->C; a.H = d->H; a.W = d->W; a.K = d->K; a.true_labels = d->true_labels; a.raw_scores = d->raw_scores;
+  a.pool_ind = (long long*)d->pool_ind;
   a.thresh = d->thresh; a.voxel = d->voxel; a.x_min = d->x_min; a.y_min = d->y_min;
   a.Kp = next_pow2(d->K);
   a.poolp = next_pow2(d->C * d->K);

@@ -5,7 +5,9 @@ An engine packs its module's parameters once per weight version (BatchNorm folde
 conv weights re-laid OIHW -> OHWI, the lidar_init rows left in place and permuted on store),
 keeps grow-only device workspaces, and issues the C-ABI calls on torch's current stream.
 Internally every activation is fp32 NHWC; NCHW exists only at the reference's API surface.
-Inference (module.eval()) only: train-mode BatchNorm raises -- see DESIGN.md "out of scope".
+These engines are the eval-mode path (BatchNorm folded from its running statistics).  Training runs through
+training.DetectorTape (train-mode BatchNorm + hand-written backward) for the whole detector; a stand-alone
+encoder / fusion / head module in train mode has no tape of its own and raises (see _check_eval).
 """
 from __future__ import annotations
 
@@ -84,9 +86,11 @@ def pack_conv(conv, bn=None, relu: bool = True, split_ok: bool = True) -> Packed
 def _check_eval(module: nn.Module) -> None:
     for m in module.modules():
         if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.training:
-            raise NotImplementedError(
-                "HIP path implements inference (eval-mode BatchNorm with running statistics); call .eval() first. "
-                "Train-mode forward/backward kernels are not built yet (DESIGN.md, 'next').")
+            raise L.BevfError(
+                f"{type(module).__name__} is in train mode: stand-alone encoder / fusion / head modules run the "
+                "eval-mode kernels only (BatchNorm folded from running statistics) -- call .eval() first.  Training "
+                "(train-mode BatchNorm, backward, optimiser) is built for the whole detector: "
+                "create_detector(...).train() routes through training.DetectorTape.")
 
 
 class _Engine:
@@ -392,10 +396,14 @@ class RadarEngine(_Engine):
             out = torch.empty(B, self.fc_w.shape[0], device=self.device)
             L.linear(per, self.fc_w, self.fc_b, out, B, K, self.fc_w.shape[0], False)
             return out
-        if method == "max":
-            return per.max(dim=1)[0]
-        if method == "mean":
-            return per.mean(dim=1)
+        if method == "max":                                          # ref src/encoders.py:654-655
+            out = torch.empty(B, feat, device=self.device)
+            L.group_max(per, out, B, R, feat)
+            return out
+        if method == "mean":                                         # ref src/encoders.py:656-657
+            out = torch.empty(B, feat, device=self.device)
+            L.cam_mean(per, out, B, R, 1, feat)
+            return out
         raise ValueError(f"Unknown fusion method: {method}")
 
 

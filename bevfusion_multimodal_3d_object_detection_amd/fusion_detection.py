@@ -29,16 +29,16 @@ _nms = _ct._nms
 
 
 def _topk(scores: torch.Tensor, K: int = 100) -> Tuple[torch.Tensor, ...]:
-    """ref :792-820: per-class top-K, then top-K of the C*K pool.  Returns (score, ind, classes, ys, xs)
-    like the reference -- `classes` is identically 0 there (index // (H*W) of an index < H*W) and here."""
+    """ref :792-820 (= src/centernet_target.py:424-452): per-class top-K of `scores` as given (no keep mask -- the
+    caller applies `_nms` first), then top-K of the flattened (C,K) pool.  Returns (score, ind, classes, ys, xs)
+    like the reference: `ind` indexes the C*K pool, `classes` is identically 0 there (index // (H*W) of an index
+    that is already < H*W) and here.  Ties go to the lower index (torch.topk leaves their order unspecified)."""
     B, Cn, H, W = scores.shape
     z = torch.zeros(B, 2, H, W, device=scores.device)
     z3 = torch.zeros(B, 3, H, W, device=scores.device)
     pred = {"heatmap": scores.float().contiguous(), "offset": z, "size": z3, "rot": z, "vel": z}
-    boxes, sc, labels, _, _ = L.centernet_decode_raw(pred, K)
-    xs = boxes[..., 0].long()
-    ys = boxes[..., 1].long()
-    return sc, ys * W + xs, labels, ys, xs
+    boxes, sc, labels, pool_ind = L.centernet_decode_raw(pred, K)
+    return sc, pool_ind, labels, boxes[..., 1].long(), boxes[..., 0].long()
 
 
 class BEVFusion(_OutOfScope):

@@ -217,8 +217,13 @@ def bn_train_forward(xraw, bn: nn.BatchNorm2d, M: int, Cc: int, res=None, relu=T
                                      res.data_ptr() if res is not None else None, y.data_ptr(), M, Cc, Cc, int(relu), _st()),
             "bevf_bn_apply_f32")
     if bn.track_running_stats and bn.running_mean is not None:           # torch: momentum 0.1, unbiased running var
-        mom = 0.1 if bn.momentum is None else bn.momentum
         nbt = bn.num_batches_tracked
+        if bn.momentum is None:
+            # torch's cumulative moving average: factor 1 / (num_batches_tracked after this batch); the count lives on
+            # the device, so this rare setting costs one host read per layer and step
+            mom = 1.0 / (int(nbt.item()) + 1) if nbt is not None else 0.0
+        else:
+            mom = bn.momentum
         _ck(_lib().bevf_bn_update_running_f32(mean.data_ptr(), var.data_ptr(), bn.running_mean.data_ptr(),
                                               bn.running_var.data_ptr(), nbt.data_ptr() if nbt is not None else None, Cc, M,
                                               float(mom), _st()), "bevf_bn_update_running_f32")
@@ -535,8 +540,10 @@ class DetectorTape:
         c0 = w0.shape[0]
         raw = _new(M * c0, dev)
         L.pointwise_smallk(rows, w0, None, enc.conv1.bias.detach(), raw, M, Cc, c0, False)
-        use_bn = isinstance(enc.bn1, nn.BatchNorm1d)
-        assert use_bn, "training path expects use_bn=True PointNet"
+        if not isinstance(enc.bn1, nn.BatchNorm1d):
+            raise L.BevfError("training: PointNetLiDAREncoder(use_bn=False) has no train-mode path on the device (the "
+                              "reference's config and default use BatchNorm, ref src/encoders.py:208-269); build it with "
+                              "use_bn=True")
         a, self.pn_bn0 = bn_train_forward(raw, enc.bn1, M, c0, relu=True)
         self.pn_layers = []
         for i in range(2, 5):
@@ -570,8 +577,8 @@ class DetectorTape:
     # -- radar: shared per-sweep MLP + max, concat -> Linear (ref src/encoders.py:628-661) --------------------------------------
     def _radar_forward(self, radars):
         renc = self.m.radar_encoder
-        if renc.fusion_method != "concat":
-            raise NotImplementedError("training is built for fusion_method='concat' (the reference's default)")
+        if renc.fusion_method not in ("concat", "max", "mean"):
+            raise ValueError(f"Unknown fusion method: {renc.fusion_method}")
         enc = renc.radar_encoder
         self.rad_sweeps = []
         feats = []
@@ -599,6 +606,18 @@ class DetectorTape:
             self.rad_sweeps.append((rows, bn0, layers, idx, (B, Np, Cc, c0, feat)))
         per = torch.stack(feats, dim=1).contiguous()                      # (B, R, feat) -- layout copy only
         B, R, feat = per.shape
+        self.rad_geom = (B, R, feat)
+        if renc.fusion_method == "max":                                   # ref src/encoders.py:654-655
+            out = _new(B * feat, per.device)
+            self.rad_fuse_idx = torch.empty(B * feat, dtype=torch.int32, device=per.device)
+            gwork = torch.empty(_lib().bevf_group_max_idx_work_bytes(B, R, feat), dtype=torch.uint8, device=per.device)
+            _ck(_lib().bevf_group_max_idx_f32(per.data_ptr(), out.data_ptr(), self.rad_fuse_idx.data_ptr(), gwork.data_ptr(),
+                                              B, R, feat, _st()), "bevf_group_max_idx_f32")
+            return out, B
+        if renc.fusion_method == "mean":                                  # ref src/encoders.py:656-657
+            out = _new(B * feat, per.device)
+            L.cam_mean(per.view(-1), out, B, R, 1, feat)
+            return out, B
         if R * feat != renc.fusion_fc.weight.shape[1]:
             raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({B}x{R * feat} and "
                                f"{renc.fusion_fc.weight.shape[1]}x{renc.fusion_fc.weight.shape[0]})")
@@ -606,9 +625,18 @@ class DetectorTape:
         return self.rad_fc.forward(per.view(-1), B), B
 
     def _radar_backward(self, dfeat, sink):
-        enc = self.m.radar_encoder.radar_encoder
-        dper = self.rad_fc.backward(dfeat, sink)                            # [B][R][feat]
-        R = len(self.rad_sweeps)
+        renc = self.m.radar_encoder
+        enc = renc.radar_encoder
+        B, R, feat = self.rad_geom
+        if renc.fusion_method == "max":            # the gradient goes to the sweep that held the maximum (first one on ties)
+            dper = _zeros(B * R * feat, dfeat.device)
+            _ck(_lib().bevf_group_max_bwd_f32(dfeat.data_ptr(), self.rad_fuse_idx.data_ptr(), dper.data_ptr(), B, R, feat, _st()),
+                "bevf_group_max_bwd_f32")
+        elif renc.fusion_method == "mean":         # every sweep receives dfeat / R
+            dper = _new(B * R * feat, dfeat.device)
+            _ck(_lib().bevf_cam_mean_bwd_f32(dfeat.data_ptr(), dper.data_ptr(), B, R, 1, feat, _st()), "bevf_cam_mean_bwd_f32")
+        else:
+            dper = self.rad_fc.backward(dfeat, sink)                        # [B][R][feat]
         for r in reversed(range(R)):
             rows, bn0, layers, idx, (B, Np, Cc, c0, feat) = self.rad_sweeps[r]
             M = B * Np
@@ -851,6 +879,13 @@ class _DetectorTrainFn(torch.autograd.Function):
 
 
 def detector_train_forward(model, imgs, pts, radars) -> Dict[str, torch.Tensor]:
+    for name, mod in model.named_modules():
+        if isinstance(mod, nn.modules.batchnorm._BatchNorm) and not mod.training:
+            # e.g. _freeze_bn() called AFTER model.train(); the reference's own order (freeze in the constructor, then
+            # model.train() in train_one_epoch, ref src/encoders.py:122-131 + src/train_detect.py:394) leaves every
+            # BatchNorm in train mode with frozen affine parameters, which is what the tape implements
+            raise L.BevfError(f"training: BatchNorm '{name}' is in eval mode inside a detector in train mode; the training "
+                              "tape normalises with batch statistics throughout (mixed-mode BatchNorm is not built)")
     params = [p for p in model.parameters() if p.requires_grad]
     outs = _DetectorTrainFn.apply(model, imgs, pts, radars, *params)
     return dict(zip(E.HEAD_BRANCHES, outs))

@@ -105,3 +105,23 @@ def compute_metrics(predictions: List[Dict], ground_truths: List[Dict]) -> Dict[
     nds = np.mean([5 * m_ap, 1 - min(m_ate / 4.0, 1.0), 1 - min(m_ase / 1.0, 1.0), 1 - min(m_aoe / np.pi, 1.0)])
     return {"mAP": float(m_ap), "NDS": float(nds),
             "AP_per_class": {CLASS_NAMES[i]: float(class_aps[i]) for i in range(len(CLASS_NAMES))}}
+
+
+def _metrics_report(metrics: Dict) -> List[str]:
+    """The lines of the drivers' metrics report: a header, mAP and NDS to four decimals, then one line per class with
+    the class name left-justified in 20 columns."""
+    lines = ["===== Evaluation Metrics =====", f"mAP : {metrics['mAP']:.4f}", f"NDS : {metrics['NDS']:.4f}", "",
+             "--- AP Per Class ---"]
+    lines += [f"{name:20s}: {ap:.4f}" for name, ap in metrics["AP_per_class"].items()]
+    return lines
+
+
+def save_and_print_metrics(metrics: dict, save_path: str = "metrics_output.txt"):
+    """ref src/utils_v2.py:208-233 (called by src/train_detect.py and src/eval.py after `compute_metrics`): print the
+    report to stdout and write the same report to `save_path` (byte-identical to the reference's file:
+    tests/golden/metrics_report_*.txt are minted from it)."""
+    lines = _metrics_report(metrics)
+    print("\n" + "\n".join(lines))
+    with open(save_path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print(f"\nMetrics saved to {save_path}")

@@ -169,9 +169,13 @@ typedef struct {
   float* velocities;   /* [B][K][2]  */
   int32_t* count;      /* [B]        entries with score > thresh (a prefix) */
   void* work;          /* scratch of bevf_centernet_decode_work_bytes(B,C,H,W,K) bytes */
+  int64_t* pool_ind;   /* [B][K] or NULL: position of each winner in the flattened (C,K) pool of per-class
+                          winners -- the second return value of the reference's _topk (ref centernet_target.py:441) */
   int32_t B, C, H, W, K;
   int32_t true_labels; /* 0: reference behaviour (label is always 0, ref centernet_target.py:434);
                           1: opt-in fix, label = class of the winning heatmap plane */
+  int32_t raw_scores;  /* 0: apply the 3x3 keep mask first (decode_centernet_predictions calls _nms, ref :352);
+                          1: rank `heat` as given (the reference's bare _topk, ref :424-452) */
   float thresh, voxel, x_min, y_min;
 } bevf_decode_desc;
 size_t bevf_centernet_decode_work_bytes(int B, int C, int H, int W, int K);

@@ -179,3 +179,36 @@ def metrics_inputs(c):
             preds.append(dict(boxes=pb.numpy(), scores=ps.numpy(), labels=pl.numpy()))
             gts.append(dict(boxes=gb.numpy(), labels=gl.numpy()))
     return preds, gts
+
+
+# ---- round 2: bare _topk, gaussian helpers, BASELINE config 1 at full size -------------------------------------------
+TOPK_CASES = [
+    dict(name="raw_s50", batch=2, h=50, w=50, K=100, seed=701),
+    dict(name="raw_s24x40_k7", batch=3, h=24, w=40, K=7, seed=702),
+]
+
+
+def topk_scores(c):
+    """An un-masked heatmap: smooth bumps, so that a peak's neighbours rank right behind it -- the case in which
+    ranking with and without the 3x3 keep mask differ."""
+    B, H, W = c["batch"], c["h"], c["w"]
+    s = c["seed"] * 104729
+    base = torch.sigmoid(synth.normal((B, 10, H, W), s + 1, 0.0, 1.5))
+    smooth = torch.nn.functional.avg_pool2d(base, 3, 1, 1, count_include_pad=False)
+    return (0.5 * base + 0.5 * smooth).contiguous()
+
+
+GAUSSIAN_2D_CASES = [((7, 7), 7 / 6), ((5, 9), 1.0), ((1, 1), 0.3), ((13, 13), 13 / 6), ((41, 41), 1.5)]
+DRAW_GAUSSIAN_CASES = [
+    dict(h=20, w=30, seed=801, splats=[((5, 5), 2, 1.0), ((0, 0), 3, 1.0), ((29, 19), 4, 1.0), ((15, 10), 6, 0.5),
+                                       ((16, 10), 2, 1.0), ((29, 0), 9, 1.0)]),
+    dict(h=8, w=8, seed=802, splats=[((4, 4), 20, 1.0), ((7, 7), 1, 2.0)]),
+]
+
+
+def draw_gaussian_canvas(c):
+    import numpy as np
+    return (synth.uniform((c["h"], c["w"]), c["seed"], 0.0, 0.3).numpy()).astype(np.float32)
+
+
+CONFIG1_CASE = dict(h=448, w=800, bev=128, stride=4, seed=901)

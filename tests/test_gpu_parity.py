@@ -294,7 +294,7 @@ def test_lidar_resize_extension_128(gpu):
 def test_standalone_modules_refuse_train_mode(gpu):
     """Train-mode BatchNorm is built for the detector (training.py); a stand-alone encoder still needs eval()."""
     m = encoders.ResNetCameraEncoder(backbone="resnet18", pretrained=False).cuda().train()
-    with pytest.raises(NotImplementedError, match="eval"):
+    with pytest.raises(RuntimeError, match="call .eval\\(\\) first"):
         m(torch.zeros(1, 3, 32, 32, device=gpu))
 
 

@@ -130,3 +130,34 @@ def test_single_process_is_a_noop():
     assert replicas.init("gloo") is None
     assert replicas.max_over_ranks(3.5, None, torch.device("cpu")) == 3.5
     assert replicas.shard_frames(5, 0, 1) == [0, 1, 2, 3, 4]
+
+
+def _run_bench(argv, extra_env=None, timeout=300):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BEVF_BENCH_STUB="1", BEVF_DIST_BACKEND="gloo", **(extra_env or {}))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, env=env, capture_output=True, text=True,
+                       timeout=timeout, cwd="/tmp")
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, lines
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` (no torchrun) must run 2 ranks -- the parent spawns them before any
+    GPU call -- and rank 0 prints ONE line with n_gpus 2.  CPU rehearsal: gloo + a stub step (BEVF_BENCH_STUB=1)."""
+    r, lines = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["steps"] == 3
+    assert lines[0]["dist"] == {"backend": "gloo", "ranks": 2}
+
+
+def test_bench_single_rank_and_world_mismatch():
+    r, lines = _run_bench(["--steps", "2"])
+    assert r.returncode == 0 and len(lines) == 1 and lines[0]["n_gpus"] == 1
+    # a launcher environment whose size differs from --gpus is refused (never a silent n_gpus that differs from the flag)
+    r, lines = _run_bench(["--gpus", "4", "--steps", "2"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0",
+                                                           "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})
+    assert r.returncode != 0 and not lines and "--gpus 4" in r.stderr
