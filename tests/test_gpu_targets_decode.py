@@ -97,4 +97,7 @@ def test_decode_true_labels_and_topk_helpers(gpu):
     sc, ind, cls, ys, xs = fd._topk(kept, K=20)
     rs, _ = torch.topk(ref.view(ref.shape[0], -1), 20, dim=1)
     assert torch.equal(sc.cpu(), rs) and int(cls.abs().max()) == 0
-    assert torch.equal(ind.cpu(), (ys * ref.shape[3] + xs).cpu())
+    # `ind` indexes the flattened (C,K) pool of per-class winners (ref src/centernet_target.py:441), not the map
+    s1, i1 = torch.topk(ref.view(ref.shape[0], ref.shape[1], -1), 20, dim=2)
+    assert torch.equal(s1.view(ref.shape[0], -1).gather(1, ind.cpu()), sc.cpu())
+    assert torch.equal(ref[torch.arange(ref.shape[0])[:, None], ind.cpu() // 20, ys.cpu(), xs.cpu()], sc.cpu())
