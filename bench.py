@@ -50,6 +50,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
 PMC_PROFILE_ROUNDS = ("r02", "r01")
+DEFAULT_CONV = "f32"
 
 
 def parse_args(argv=None):
@@ -66,6 +67,10 @@ def parse_args(argv=None):
                     help="fp32 (default): exact fp32 MFMA.  bf16 = BASELINE configs 3/5: bf16 storage, fp32 accumulate.  "
                          "f32x3: fp32 storage, convolutions through an exact 3-way bf16 split on the bf16 MFMA "
                          "(fp32-level error, not bit-identical to fp32; opt-in, never the headline)")
+    ap.add_argument("--conv", choices=["wino", "f32"], default=DEFAULT_CONV,
+                    help="fp32 convolution kernels: f32 = exact implicit GEMM (v_mfma_f32_32x32x2_f32) everywhere; wino = fused fp32 "
+                         "Winograd F(2x2,3x3) for the 3x3 / stride 1 layers (fp32 products and accumulation, 2.25x fewer MFMA FLOPs, "
+                         "a few 1e-7 relative from the exact kernel), exact implicit GEMM for the rest")
     ap.add_argument("--graph", action="store_true", help="replay the inference forward as one hipGraph (small batches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true", help="skip the per-launch HIP-event brackets")
@@ -177,7 +182,7 @@ def cpu_baseline(cfg, state_dict, budget_s=12.0):
                 sample=f"{n} frames at B=1 after 1 warm-up, oracle/ref_model.py (PyTorch-CPU fp32), same config")
 
 
-def run_leg(config, dtype, mode, batch, steps, warmup, ctx, graph=False, kernel_timer=True, keep_state=False):
+def run_leg(config, dtype, mode, batch, steps, warmup, ctx, graph=False, kernel_timer=True, keep_state=False, conv="f32"):
     """One timed leg: W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both
     sides, MAX over ranks.  Returns the leg's record (value = whole-job frames/s) and, if asked, the state dict."""
     import torch
@@ -187,7 +192,7 @@ def run_leg(config, dtype, mode, batch, steps, warmup, ctx, graph=False, kernel_
     model_cpu = build_model(cfg)
     state = {k: v.clone() for k, v in model_cpu.state_dict().items()} if keep_state else None
     model = model_cpu.to(dev)
-    engine.set_conv_mode("f32x3" if dtype == "f32x3" else "f32")
+    engine.set_conv_mode("f32x3" if dtype == "f32x3" else (conv if (dtype == "fp32" and mode == "infer") else "f32"))
     if dtype == "bf16":
         model = model.bfloat16()
     seed = replicas.frame_seed(0x5EED, config if mode == "train" else 2, rank)     # inference legs share config 2's images
@@ -272,6 +277,11 @@ def run_leg(config, dtype, mode, batch, steps, warmup, ctx, graph=False, kernel_
     if timer is not None:
         tot = timer.totals()
         conv = tot.get("conv_igemm_f32")
+        wino = tot.get("conv_wino_f32")
+        executed = conv["flops"] if conv else 0.0                 # FLOPs the matrix pipe really executes
+        if wino:                                                  # Winograd F(2x2,3x3): 16 multiplies per 36 algorithmic ones
+            executed += wino["flops"] * 16.0 / 36.0
+            conv = {k: conv[k] + wino[k] for k in conv} if conv else wino
         if conv and mode == "train":                          # forward + data-gradient + weight-gradient GEMMs
             for extra in ("conv_dgrad_f32", "conv_wgrad_f32"):
                 e = tot.get(extra)
@@ -282,6 +292,8 @@ def run_leg(config, dtype, mode, batch, steps, warmup, ctx, graph=False, kernel_
             # f32x3 spends six bf16 MFMA products per algorithmic multiply-add: its ceiling is a sixth of the bf16 peak
             peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "f32x3": PEAK_BF16_MFMA_TFLOPS / 6.0}[dtype]
             kname = {"fp32": "conv_igemm_f32", "bf16": "conv_igemm_bf16", "f32x3": "conv_split_f32x3"}[dtype]
+            if wino:
+                kname = "conv_wino_f32+conv_igemm_f32"
             rec["roofline"] = {"kernel": kname if mode == "infer" else "conv_igemm_f32+conv_wgrad_f32",
                                "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                "traffic": None, "traffic_source": None,
@@ -290,6 +302,11 @@ def run_leg(config, dtype, mode, batch, steps, warmup, ctx, graph=False, kernel_
                                "gflop_per_step": conv["flops"] / timer_steps / 1e9,
                                "share_of_step": conv["ms"] / (1e3 * timer_elapsed),
                                "measured_over": "the timed region" if timer_in_region else "2 untimed steps after the timed region"}
+            if wino:
+                # `achieved` counts ALGORITHMIC (direct-convolution) FLOPs, as SURVEY.md 8d tabulates them; the Winograd layers
+                # execute 16/36 of theirs, so the matrix pipe's own utilisation is reported beside it
+                ex = executed / (conv["ms"] * 1e-3) / 1e12
+                rec["roofline"]["executed"] = {"tflops": ex, "frac": ex / peak, "wino_share_of_flops": wino["flops"] / conv["flops"]}
             tr = pmc_traffic(config, batch) if dtype == "fp32" and mode == "infer" else None
             if tr is not None:
                 rec["roofline"]["traffic"], rec["roofline"]["traffic_source"] = tr
@@ -365,7 +382,7 @@ def main():
     ctx = dict(dev=dev, dist=dist, rank=rank, world=world, inputs=InputCache(dev))
 
     head, state = run_leg(args.config, args.dtype, args.mode, args.batch, args.steps, args.warmup, ctx,
-                          graph=args.graph, kernel_timer=not args.no_kernel_timer, keep_state=True)
+                          graph=args.graph, kernel_timer=not args.no_kernel_timer, keep_state=True, conv=args.conv)
 
     extras = []
     if args.extras != "none" and not args.graph:
@@ -391,6 +408,7 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": cfg["name"], "batch_per_gpu": args.batch,
                        "parallelism": f"replicas x{world}" if args.mode == "infer" else f"dp{world}",
+                       "conv_kernels": args.conv if args.dtype == "fp32" and args.mode == "infer" else "f32",
                        "weights": "random-init (synthetic, seeded)", "launch": "hipGraph replay" if args.graph else "eager",
                        "mode": head["mode"]},
             # ranks of the process group the barrier / MAX (and, in training legs, the gradient all-reduce) ran on

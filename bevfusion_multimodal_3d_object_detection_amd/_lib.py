@@ -100,6 +100,9 @@ SIGNATURES = {
     "bevf_nchw_to_nhwc_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_nhwc_to_nchw_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_fill_f32": (C.c_int, [C.c_void_p, C.c_float, C.c_size_t, C.c_void_p]),
+    "bevf_wino_filter_floats": (C.c_size_t, [C.c_int] * 2),
+    "bevf_wino_filter_transform_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 2 + [C.c_void_p]),
+    "bevf_conv3x3_wino_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "bevf_centernet_decode_work_bytes": (C.c_size_t, [C.c_int] * 5),
     "bevf_centernet_decode_f32": (C.c_int, [C.POINTER(DecodeDesc), C.c_void_p]),
     "bevf_centernet_targets_f32": (C.c_int, [C.POINTER(TargetsDesc), C.c_void_p]),
@@ -240,6 +243,36 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, scale, shift, y: Optional[torc
                  N, H, W, Cin, x_cs, Ho, Wo, Cout, y_cs, res_cs, KH, KW, stride, pad, int(relu), rows_per_group, tile)
     fn = "bevf_conv2d_nhwc_f32x3" if split else "bevf_conv2d_nhwc_" + _sfx(x)
     _check(getattr(lib(), fn)(C.byref(d), _stream()), fn)
+
+
+def wino_filter_transform(w_ohwi: torch.Tensor, Cout: int, Cin: int) -> torch.Tensor:
+    """fp32 OHWI 3x3 filter -> the transformed-filter image of bevf_conv3x3_wino_f32."""
+    w_ohwi = w_ohwi.contiguous()
+    if w_ohwi.numel() != Cout * 9 * Cin:
+        raise BevfError(f"wino_filter_transform: filter has {w_ohwi.numel()} elements, expected {Cout * 9 * Cin}")
+    u = torch.empty(lib().bevf_wino_filter_floats(Cout, Cin), dtype=torch.float32, device=w_ohwi.device)
+    _check(lib().bevf_wino_filter_transform_f32(_pc(w_ohwi), _p(u), Cout, Cin, _stream()), "bevf_wino_filter_transform_f32")
+    return u
+
+
+def conv3x3_wino(x: torch.Tensor, u: torch.Tensor, scale, shift, y: torch.Tensor, *, N: int, H: int, W: int, Cin: int,
+                 x_cs: int, Cout: int, y_cs: int, relu: bool, res: Optional[torch.Tensor] = None, res_cs: int = 0) -> None:
+    """3x3 / stride 1 / pad 1 convolution as fused fp32 Winograd F(2x2,3x3); `u` from wino_filter_transform."""
+    M = N * H * W
+    if x.numel() < (M - 1) * x_cs + Cin:
+        raise BevfError("conv_wino: input buffer smaller than N*H*W*x_cs")
+    if u.numel() != lib().bevf_wino_filter_floats(Cout, Cin):
+        raise BevfError("conv_wino: transformed filter has the wrong size")
+    if y.numel() < (M - 1) * y_cs + Cout:
+        raise BevfError("conv_wino: output buffer too small")
+    if res is not None and res.numel() < (M - 1) * res_cs + Cout:
+        raise BevfError("conv_wino: residual buffer too small")
+    for v in (scale, shift):
+        if v is not None and v.numel() != Cout:
+            raise BevfError("conv_wino: scale/shift length != Cout")
+    d = ConvDesc(_p(x), _pc(u), _pc(scale), _pc(shift), _p(res), _p(y), None, N, H, W, Cin, x_cs, H, W, Cout, y_cs, res_cs,
+                 3, 3, 1, 1, int(relu), 0, 0)
+    _check(lib().bevf_conv3x3_wino_f32(C.byref(d), _stream()), "bevf_conv3x3_wino_f32")
 
 
 def split_weights_f32x3(w: torch.Tensor) -> torch.Tensor:

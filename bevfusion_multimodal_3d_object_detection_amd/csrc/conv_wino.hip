@@ -1,63 +1,52 @@
-// Prototype + microbenchmark: fp32 Winograd F(2x2,3x3) convolution on v_mfma_f32_16x16x4_f32 (gfx950), fully fused
-// (input transform in registers from a raw LDS patch, 16 "frequency" GEMMs on the matrix pipe, output transform in
-// registers) -- the measurement VERDICT r1 item 7 asks for.  Stand-alone: builds with hipcc, runs on the GPU box.
+// fp32 Winograd F(2x2,3x3) convolution (3x3, stride 1, pad 1) on v_mfma_f32_16x16x4_f32, gfx950 -- fully fused:
+// input transform in registers from a raw LDS patch, the 16 "frequency" GEMMs on the matrix pipe, output transform
+// in registers, the same fused epilogue as conv_igemm (folded BN scale/shift, residual, ReLU, channel-strided store).
 //
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/wino_proto.hip -o gpurun_out/wino_proto && gpurun_out/wino_proto
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A      per 2x2 output tile, summed over input channels
+//
+// 16 multiplies per 4 outputs instead of 36: 2.25x fewer MFMA FLOPs than the implicit GEMM, and the fp32 MFMA pipe is
+// what bounds these layers.  The products are fp32 FMAs with fp32 accumulation like the direct kernel;
+// what changes is the summation structure, so results agree with it to a few 1e-7 relative, not bit for bit.
 //
 // Workgroup = 256 threads = 4 waves = 8x8 Winograd tiles (16x16 output pixels) x 64 output channels.  Wave w owns
-// tile rows 2w, 2w+1 (16 tiles) x 64 channels x all 16 frequencies: 64 accumulator tiles of 16x16 (256 AGPRs).
-// K loop over groups of 8 input channels = 2 MFMA k-steps: lane (t = l&15, kq = l>>4) reads its tile's 4x4 patch for
-// channels 2kq, 2kq+1 (16 ds_read_b64), transforms it (64 VALU) into the A fragments of all 16 frequencies; B fragments
-// (pre-transformed filters, laid out in HBM in the exact LDS image order) are staged per group by LDS-DMA.
-#include <hip/hip_runtime.h>
+// tile rows 2w, 2w+1 (16 tiles) x 64 channels x all 16 frequencies: 64 accumulator tiles of 16x16 = all 256 AGPRs
+// (one wave per SIMD).  K loop over groups of 8 input channels = 2 MFMA k-steps of 128 MFMAs:
+//   * A side: the 18x18-pixel input patch sits in LDS as raw NHWC rows (32-channel chunks, double-buffered, staged
+//     global -> registers -> LDS with out-of-range pixels answered by the buffer unit with zeros); lane (t = l&15,
+//     kq = l>>4) reads its tile's 4x4 patch for channels 2kq, 2kq+1 (16 ds_read_b64) and transforms it (64 VALU)
+//     into the A fragments of all 16 frequencies, one group ahead of their use;
+//   * B side: the transformed filters are stored in HBM in the exact LDS image order per (64-channel slab, group),
+//     so staging is a straight 32 KB LDS-DMA copy (global_load_lds), double-buffered; fragments are ds_read_b128,
+//     bank-conflict-free.
+// With one wave per SIMD nothing else fills an issue gap, so every non-MFMA instruction is pinned BETWEEN two MFMAs
+// (one small piece per gap, sched_barrier after each) and issues in the shadow of the MFMA executing.  The MFMAs are
+// inline asm with "+a" accumulators: with the builtin, hipcc's allocator moved accumulators between AGPRs and VGPRs
+// inside the loop (44-296 v_accvgpr moves per group); pinned, the loop has none and no spills.
+#include "conv_common.h"
 
-#include <chrono>
-#include <cmath>
-#include <cstdint>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
 #include <type_traits>
-#include <vector>
 
-#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+namespace {
 
-#ifndef ASM_MFMA
-#define ASM_MFMA 1
-#endif
-#ifndef VAR
-#define VAR 0
-#endif
-#if ASM_MFMA
-#define MFMA(acc_, a_, b_) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc_) : "v"(a_), "v"(b_))
-#else
-#define MFMA(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b_, acc_, 0, 0, 0)
-#endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-constexpr unsigned kOob = 0x80000000u;
+
+#define MFMA(acc_, a_, b_) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc_) : "v"(a_), "v"(b_))
 
 struct WinoArgs {
   const float* x;      // NHWC, channel stride x_cs
-  const float* u;      // [ct][G][16 f][4 nb][16 n][8 cin]
+  const float* u;      // [ct][G][16 f][2 nb pair][2 kh][16 n][2][2 nb][2 cin]: bevf_wino_filter_transform_f32
   const float* scale;  // [Cout] or null
   const float* shift;
   const float* res;    // NHWC residual or null
   float* y;
-  int N, H, W, Cin, x_cs, Cout, y_cs, res_cs, relu;
-  int TBY, TBX, nct;   // tile blocks per image (rows, cols), cout tiles
+  int N, H, W, Cin, x_cs, Cout, y_cs, res_cs;
+  int TBY, TBX, nct;   // tile blocks per image (rows, cols), 64-channel slabs
 };
 
 constexpr int PIX = 18 * 18, PITCH = 36;                       // patch pixels, floats per pixel in LDS (32 + 4 pad)
 constexpr int PATCH_FLOATS = PIX * PITCH;                      // 11664 floats = 46656 B
 constexpr int BG_FLOATS = 16 * 4 * 16 * 8;                     // 8192 floats = 32 KB per channel group
 constexpr int LDS_BYTES = (2 * PATCH_FLOATS + 2 * BG_FLOATS) * 4;
-
-__device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
-  return __builtin_bit_cast(f32x4, v);
-}
 
 template <bool RES, bool RELU>
 __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
@@ -127,7 +116,7 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
   // ---- prologue: first tile's patch chunk 0, B group 0, A fragments of group 0 -----------------------------------------
   int tile = blockIdx.x;
   unsigned pv[11], pvl[11];
-  int n, by, bx, ct, nn, nby, nbx, nct_;
+  int n, by, bx, ct;
   make_pv(tile, pv, n, by, bx, ct);
 #pragma unroll
   for (int i = 0; i < 8; ++i) dma_piece(ub + (size_t)ct * G * BG_FLOATS, 0, i);
@@ -285,121 +274,87 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
   }
 }
 
-// ---- host side ------------------------------------------------------------------------------------------------------
-static uint64_t rng_state = 0x1234567ull;
-static float frand() {
-  rng_state = rng_state * 6364136223846793005ull + 1442695040888963407ull;
-  return (float)((rng_state >> 33) & 0xFFFFFF) / (float)0x1000000 * 2.f - 1.f;
-}
 
-// filters OIHW [Cout][Cin][3][3] -> U image [ct][G][16][4][16][8]
-static std::vector<float> transform_filters(const std::vector<float>& w, int Cout, int Cin) {
-  const int nct = (Cout + 63) / 64, G = Cin / 8;
-  std::vector<float> u((size_t)nct * G * 8192, 0.f);
+// OHWI filters [Cout][3][3][Cin] -> U image [ct][G][16 f][2 np][2 kh][16 n][2][2 nbl][2 cin]; U = G g G^T in double
+__global__ __launch_bounds__(256) void wino_filter_transform(const float* __restrict__ w, float* __restrict__ u, int Cout,
+                                                             int Cin, int nct) {
+  const long long idx = blockIdx.x * 256ll + threadIdx.x;
+  const long long total = (long long)nct * 64 * Cin;
+  if (idx >= total) return;
+  const int ci = (int)(idx % Cin), co = (int)(idx / Cin);
+  double g[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) g[i][j] = co < Cout ? (double)w[(((size_t)co * 3 + i) * 3 + j) * Cin + ci] : 0.0;
   const double Gm[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
-  for (int co = 0; co < Cout; ++co)
-    for (int ci = 0; ci < Cin; ++ci) {
-      const float* g = &w[((size_t)co * Cin + ci) * 9];
-      double tmp[4][3], U[4][4];
-      for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 3; ++j) tmp[i][j] = Gm[i][0] * g[0 * 3 + j] + Gm[i][1] * g[1 * 3 + j] + Gm[i][2] * g[2 * 3 + j];
-      for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) U[i][j] = tmp[i][0] * Gm[j][0] + tmp[i][1] * Gm[j][1] + tmp[i][2] * Gm[j][2];
-      const int ct = co / 64, nb = (co % 64) / 16, nn = co % 16, g8 = ci / 8, q = ci % 8;
-      for (int f = 0; f < 16; ++f)
-        u[((((size_t)ct * G + g8) * 16 + f) * 2 + (nb >> 1)) * 256 + ((q >> 2) * 16 + nn) * 8 + ((q >> 1) & 1) * 4 + (nb & 1) * 2 + (q & 1)] = (float)U[f >> 2][f & 3];
-    }
-  return u;
+  double tmp[4][3], U[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) tmp[i][j] = Gm[i][0] * g[0][j] + Gm[i][1] * g[1][j] + Gm[i][2] * g[2][j];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) U[i][j] = tmp[i][0] * Gm[j][0] + tmp[i][1] * Gm[j][1] + tmp[i][2] * Gm[j][2];
+  const int G = Cin >> 3, ct = co >> 6, nb = (co & 63) >> 4, nn = co & 15, g8 = ci >> 3, q = ci & 7;
+#pragma unroll
+  for (int f = 0; f < 16; ++f)
+    u[((((size_t)ct * G + g8) * 16 + f) * 2 + (nb >> 1)) * 256 + ((q >> 2) * 16 + nn) * 8 + ((q >> 1) & 1) * 4 + (nb & 1) * 2 + (q & 1)] =
+        (float)U[f >> 2][f & 3];
 }
 
-static void cpu_conv(const std::vector<float>& x, const std::vector<float>& w, std::vector<double>& y, int N, int H, int W, int Cin, int Cout) {
-  y.assign((size_t)N * H * W * Cout, 0.0);
-  for (int n = 0; n < N; ++n)
-    for (int oy = 0; oy < H; ++oy)
-      for (int ox = 0; ox < W; ++ox)
-        for (int co = 0; co < Cout; ++co) {
-          double s = 0;
-          for (int kh = 0; kh < 3; ++kh)
-            for (int kw = 0; kw < 3; ++kw) {
-              const int iy = oy + kh - 1, ix = ox + kw - 1;
-              if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-              const float* xp = &x[(((size_t)n * H + iy) * W + ix) * Cin];
-              const float* wp = &w[(size_t)co * Cin * 9 + kh * 3 + kw];
-              for (int ci = 0; ci < Cin; ++ci) s += (double)xp[ci] * wp[(size_t)ci * 9];
-            }
-          y[(((size_t)n * H + oy) * W + ox) * Cout + co] = s;
-        }
+}  // namespace
+
+extern "C" size_t bevf_wino_filter_floats(int Cout, int Cin) {
+  return (size_t)((Cout + 63) / 64) * 64 * 16 * (size_t)Cin;
 }
 
-static double run(int N, int H, int W, int Cin, int Cout, bool check, int iters) {
-  std::vector<float> x((size_t)N * H * W * Cin), w((size_t)Cout * Cin * 9), scale(Cout), shift(Cout);
-  for (auto& v : x) v = fmaxf(frand() * 3.f, 0.f);              // post-ReLU-like activations
-  const float ws = sqrtf(2.f / (9.f * Cin));
-  for (auto& v : w) v = frand() * ws * 1.7f;
-  for (int i = 0; i < Cout; ++i) { scale[i] = 0.8f + 0.4f * fabsf(frand()); shift[i] = 0.1f * frand(); }
-  std::vector<float> u = transform_filters(w, Cout, Cin);
-  float *dx, *du, *dy, *dsc, *dsh;
-  CK(hipMalloc(&dx, x.size() * 4)); CK(hipMalloc(&du, u.size() * 4)); CK(hipMalloc(&dy, (size_t)N * H * W * Cout * 4));
-  CK(hipMalloc(&dsc, Cout * 4)); CK(hipMalloc(&dsh, Cout * 4));
-  CK(hipMemcpy(dx, x.data(), x.size() * 4, hipMemcpyHostToDevice));
-  CK(hipMemcpy(du, u.data(), u.size() * 4, hipMemcpyHostToDevice));
-  CK(hipMemcpy(dsc, scale.data(), Cout * 4, hipMemcpyHostToDevice));
-  CK(hipMemcpy(dsh, shift.data(), Cout * 4, hipMemcpyHostToDevice));
-  CK(hipMemset(dy, 0xFF, (size_t)N * H * W * Cout * 4));
+extern "C" int bevf_wino_filter_transform_f32(const float* w_ohwi, float* u, int Cout, int Cin, void* stream) {
+  BEVF_REQUIRE(w_ohwi && u, "wino_filter_transform: null pointer");
+  BEVF_REQUIRE(Cout > 0 && Cin > 0 && Cin % 32 == 0, "wino_filter_transform: Cin=%d must be a positive multiple of 32", Cin);
+  const int nct = (Cout + 63) / 64;
+  const long long total = (long long)nct * 64 * Cin;
+  hipLaunchKernelGGL(wino_filter_transform, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     w_ohwi, u, Cout, Cin, nct);
+  return bevf_check_launch("bevf_wino_filter_transform_f32");
+}
+
+extern "C" int bevf_conv3x3_wino_f32(const bevf_conv_desc* d, void* stream) {
+  BEVF_REQUIRE(d && d->x && d->w && d->y, "conv_wino: null x / w / y");
+  BEVF_REQUIRE(d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1, "conv_wino: 3x3, stride 1, pad 1 only (got %dx%d s%d p%d)",
+               d->KH, d->KW, d->stride, d->pad);
+  BEVF_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cout > 0 && d->Ho == d->H && d->Wo == d->W, "conv_wino: bad shape");
+  BEVF_REQUIRE(d->Cin > 0 && d->Cin % 32 == 0, "conv_wino: Cin=%d must be a positive multiple of 32", d->Cin);
+  BEVF_REQUIRE(d->x_cs >= d->Cin && d->x_cs % 4 == 0 && d->y_cs >= d->Cout, "conv_wino: channel strides");
+  BEVF_REQUIRE(!d->res || d->res_cs >= d->Cout, "conv_wino: res_cs < Cout");
+  BEVF_REQUIRE(!d->colmax, "conv_wino: the fused column max belongs to the 1x1 layers (bevf_conv2d_nhwc_f32)");
+  BEVF_REQUIRE(bevf_aligned16(d->x) && bevf_aligned16(d->w), "conv_wino: x / w must be 16-byte aligned");
+  BEVF_REQUIRE((long long)d->N * d->H * d->W * d->x_cs * 4 < (1ll << 31) && (long long)d->N * d->H * d->W * d->y_cs * 4 < (1ll << 31) &&
+                   (!d->res || (long long)d->N * d->H * d->W * d->res_cs * 4 < (1ll << 31)),
+               "conv_wino: activations must stay below 2 GiB (32-bit buffer offsets)");
   WinoArgs a;
-  a.x = dx; a.u = du; a.scale = dsc; a.shift = dsh; a.res = nullptr; a.y = dy;
-  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.x_cs = Cin; a.Cout = Cout; a.y_cs = Cout; a.res_cs = 0; a.relu = check ? 0 : 1;
-  a.TBY = (H + 15) / 16; a.TBX = (W + 15) / 16; a.nct = (Cout + 63) / 64;
-  const int ntiles = N * a.TBY * a.TBX * a.nct;
-  const int grid = ntiles;
-  auto kern = check ? wino_f32<false, false> : wino_f32<false, true>;
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS_BYTES, 0, a);
-  CK(hipDeviceSynchronize());
-  double worst = 0;
-  if (check) {
-    std::vector<float> y((size_t)N * H * W * Cout);
-    CK(hipMemcpy(y.data(), dy, y.size() * 4, hipMemcpyDeviceToHost));
-    std::vector<double> ref;
-    cpu_conv(x, w, ref, N, H, W, Cin, Cout);
-    double mx = 0;
-    for (size_t i = 0; i < ref.size(); ++i) {
-      const double r = ref[i] * scale[i % Cout] + shift[i % Cout];
-      mx = fmax(mx, fabs(r));
-      worst = fmax(worst, fabs((double)y[i] - r));
-    }
-    printf("check N=%d %dx%d Cin=%d Cout=%d: max|err| %.3e  max|ref| %.3e  rel %.3e\n", N, H, W, Cin, Cout, worst, mx, worst / mx);
+  a.x = d->x; a.u = d->w; a.scale = d->scale; a.shift = d->shift; a.res = d->res; a.y = d->y;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.x_cs = d->x_cs; a.Cout = d->Cout; a.y_cs = d->y_cs; a.res_cs = d->res_cs;
+  a.TBY = (d->H + 15) / 16; a.TBX = (d->W + 15) / 16; a.nct = (d->Cout + 63) / 64;
+  const long long ntiles = (long long)d->N * a.TBY * a.TBX * a.nct;
+  BEVF_REQUIRE(ntiles < (1ll << 31), "conv_wino: too many tiles");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_f32<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_f32<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_f32<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_f32<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    attr_done = true;
   }
-  if (iters > 0) {
-    hipEvent_t e0, e1;
-    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS_BYTES, 0, a);
-    CK(hipEventRecord(e0));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS_BYTES, 0, a);
-    CK(hipEventRecord(e1));
-    CK(hipEventSynchronize(e1));
-    float ms;
-    CK(hipEventElapsedTime(&ms, e0, e1));
-    ms /= iters;
-    const double flops = 2.0 * N * H * W * Cout * 9.0 * Cin;
-    printf("bench N=%d %dx%d Cin=%d Cout=%d: %.3f ms  %.1f TF direct-equivalent (%d tiles)\n", N, H, W, Cin, Cout, ms,
-           flops / ms * 1e-9, ntiles);
-    worst = ms;
+  const dim3 grid((unsigned)ntiles), block(256);
+  if (d->res) {
+    if (d->relu) hipLaunchKernelGGL((wino_f32<true, true>), grid, block, LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((wino_f32<true, false>), grid, block, LDS_BYTES, st, a);
+  } else {
+    if (d->relu) hipLaunchKernelGGL((wino_f32<false, true>), grid, block, LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((wino_f32<false, false>), grid, block, LDS_BYTES, st, a);
   }
-  CK(hipFree(dx)); CK(hipFree(du)); CK(hipFree(dy)); CK(hipFree(dsc)); CK(hipFree(dsh));
-  return worst;
-}
-
-int main(int argc, char** argv) {
-  printf("VAR=%d\n", VAR);
-  run(2, 13, 21, 64, 64, true, 0);
-  run(1, 33, 18, 96, 80, true, 0);
-  if (argc > 1 && !strcmp(argv[1], "check")) return 0;
-  run(48, 225, 400, 64, 64, false, 10);      // ResNet layer1 at B=8
-  run(48, 113, 200, 128, 128, false, 10);    // layer2
-  run(48, 57, 100, 256, 256, false, 10);     // layer3
-  run(8, 128, 128, 512, 512, false, 10);     // bev_fusion conv1 (M=2)
-  run(8, 128, 128, 512, 256, false, 10);     // bev_fusion conv2
-  run(8, 128, 128, 256, 320, false, 10);     // fused head conv
-  return 0;
+  return bevf_check_launch("bevf_conv3x3_wino_f32");
 }

@@ -45,6 +45,7 @@ class PackedConv:
     stride: int
     pad: int
     relu: bool
+    wino: bool = False       # w is the transformed-filter image of the fused Winograd kernel (csrc/conv_wino.hip)
 
 
 _CONV_MODE = "f32"
@@ -52,12 +53,14 @@ _CONV_MODE = "f32"
 
 def set_conv_mode(mode: str) -> None:
     """How fp32 models multiply in their convolutions.  "f32" (default): v_mfma_f32_32x32x2_f32, an exact fp32 FMA
-    chain.  "f32x3": opt-in, fp32 operands split exactly into three bf16 planes and multiplied on the bf16 MFMA
+    chain.  "wino": the 3x3 / stride 1 / pad 1 layers (Cin % 32 == 0) run as fused fp32 Winograd F(2x2,3x3) on
+    v_mfma_f32_16x16x4_f32 (csrc/conv_wino.hip: fp32 products and accumulation, 2.25x fewer of them, a few 1e-7
+    relative from the direct kernel); every other layer as "f32".  "f32x3": opt-in, fp32 operands split exactly into three bf16 planes and multiplied on the bf16 MFMA
     (six partial products, fp32 accumulate; csrc/conv_split.hip) -- fp32-level error, ~1.3-1.4x faster, not
     bit-identical to the default.  Engines repack on the next forward."""
     global _CONV_MODE
-    if mode not in ("f32", "f32x3"):
-        raise ValueError(f"conv mode must be 'f32' or 'f32x3', got {mode!r}")
+    if mode not in ("f32", "wino", "f32x3"):
+        raise ValueError(f"conv mode must be 'f32', 'wino' or 'f32x3', got {mode!r}")
     _CONV_MODE = mode
 
 
@@ -78,9 +81,17 @@ def pack_conv(conv, bn=None, relu: bool = True, split_ok: bool = True) -> Packed
     pad = conv.padding[0] if isinstance(conv.padding, tuple) else conv.padding
     scale, shift = _bn_fold(conv.bias, bn, cout, w.device)
     packed = w.permute(0, 2, 3, 1).contiguous().view(-1)
-    if _CONV_MODE == "f32x3" and split_ok and packed.dtype == torch.float32 and cin % 32 == 0:
-        packed = L.split_weights_f32x3(packed)
-    return PackedConv(packed, scale, shift, cin, cout, kh, stride, pad, relu)
+    return _finish_pack(packed, scale, shift, cin, cout, kh, stride, pad, relu, split_ok)
+
+
+def _finish_pack(packed, scale, shift, cin, cout, k, stride, pad, relu, split_ok=True) -> PackedConv:
+    """OHWI filter -> what the active conv mode's kernel reads."""
+    if packed.dtype == torch.float32 and cin % 32 == 0:
+        if _CONV_MODE == "wino" and (k, stride, pad) == (3, 1, 1):
+            return PackedConv(L.wino_filter_transform(packed, cout, cin), scale, shift, cin, cout, k, stride, pad, relu, wino=True)
+        if _CONV_MODE == "f32x3" and split_ok:
+            packed = L.split_weights_f32x3(packed)
+    return PackedConv(packed, scale, shift, cin, cout, k, stride, pad, relu)
 
 
 def _check_eval(module: nn.Module) -> None:
@@ -191,12 +202,17 @@ def _span(name: str, flops: float = 0.0, nbytes: float = 0.0):
 
 def _run_conv(pc: PackedConv, x, y, N, H, W, x_cs=None, y_cs=None, res=None, colmax=None, rows_per_group=0, tile=0):
     ho, wo = (H + 2 * pc.pad - pc.k) // pc.stride + 1, (W + 2 * pc.pad - pc.k) // pc.stride + 1
-    with _span("conv_igemm_f32", flops=2.0 * N * ho * wo * pc.cout * pc.k * pc.k * pc.cin):
+    flops = 2.0 * N * ho * wo * pc.cout * pc.k * pc.k * pc.cin          # algorithmic (direct convolution)
+    with _span("conv_wino_f32" if pc.wino else "conv_igemm_f32", flops=flops):
         _conv_call(pc, x, y, N, H, W, x_cs, y_cs, res, colmax, rows_per_group, tile)
     return ho, wo
 
 
 def _conv_call(pc: PackedConv, x, y, N, H, W, x_cs=None, y_cs=None, res=None, colmax=None, rows_per_group=0, tile=0):
+    if pc.wino:
+        L.conv3x3_wino(x, pc.w, pc.scale, pc.shift, y, N=N, H=H, W=W, Cin=pc.cin, x_cs=x_cs or pc.cin, Cout=pc.cout,
+                       y_cs=y_cs or pc.cout, relu=pc.relu, res=res, res_cs=pc.cout if res is not None else 0)
+        return
     L.conv2d_nhwc(x, pc.w, pc.scale, pc.shift, y, N=N, H=H, W=W, Cin=pc.cin, x_cs=x_cs or pc.cin, Cout=pc.cout,
                   y_cs=y_cs or pc.cout, KH=pc.k, KW=pc.k, stride=pc.stride, pad=pc.pad, relu=pc.relu, res=res,
                   res_cs=pc.cout if res is not None else 0, colmax=colmax, rows_per_group=rows_per_group, tile=tile)
@@ -531,8 +547,8 @@ class HeadEngine(_Engine):
         w3 = torch.cat([c.weight.detach() for c in convs3], dim=0)                 # (5*hc, Cin, 3, 3)
         b3 = torch.cat([c.bias.detach() for c in convs3], dim=0)
         self.hc = convs3[0].weight.shape[0]
-        self.conv = PackedConv(w3.permute(0, 2, 3, 1).contiguous().view(-1), None, b3.float().contiguous(),
-                               w3.shape[1], w3.shape[0], 3, 1, 1, True)
+        self.conv = _finish_pack(w3.permute(0, 2, 3, 1).contiguous().view(-1), None, b3.float().contiguous(),
+                                 w3.shape[1], w3.shape[0], 3, 1, 1, True)
         self.cs = [c.weight.shape[0] for c in convs1]
         self.w1 = torch.cat([c.weight.detach().reshape(c.weight.shape[0], self.hc) for c in convs1], 0).float().contiguous()
         self.b1 = torch.cat([c.bias.detach() for c in convs1], 0).float().contiguous()

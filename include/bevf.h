@@ -67,6 +67,17 @@ typedef struct {
 } bevf_conv_desc;
 int bevf_conv2d_nhwc_f32(const bevf_conv_desc* d, void* stream);
 
+/* The same convolution for the 3x3 / stride 1 / pad 1 layers (ResNet blocks, camera_proj, lidar_upsample, radar_refine,
+ * bev_fusion, the fused CenterNet 3x3: ~90 % of the path's FLOPs) as fp32 Winograd F(2x2,3x3), fully fused, on
+ * v_mfma_f32_16x16x4_f32: 16 multiplies per 2x2 outputs instead of 36.  fp32 products and fp32 accumulation as in the
+ * direct kernel, a different summation structure: agrees with it to a few 1e-7 relative, not bit for bit.
+ * `d->w` is the transformed-filter image made by bevf_wino_filter_transform_f32 from the OHWI filter
+ * (bevf_wino_filter_floats(Cout, Cin) floats); everything else in the descriptor means what it means above
+ * (colmax unsupported, `tile` ignored).  Requires KH = KW = 3, stride 1, pad 1, Cin % 32 == 0. */
+size_t bevf_wino_filter_floats(int Cout, int Cin);
+int bevf_wino_filter_transform_f32(const float* w_ohwi, float* u, int Cout, int Cin, void* stream);
+int bevf_conv3x3_wino_f32(const bevf_conv_desc* d, void* stream);
+
 /* ResNet stem: 7x7 stride-2 pad-3 conv on a planar 3-channel image + BN (+ ReLU when relu != 0),
  * ref src/encoders.py:154-156 (torchvision conv1/bn1/relu).  x: [N][3][H][W] (NCHW, as the
  * reference's callers hand it over), w: the filter bank packed k-major [148][64] with
