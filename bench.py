@@ -50,7 +50,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
 PMC_PROFILE_ROUNDS = ("r02", "r01")
-DEFAULT_CONV = "f32"
+DEFAULT_CONV = "wino"
 
 
 def parse_args(argv=None):
@@ -192,7 +192,7 @@ def run_leg(config, dtype, mode, batch, steps, warmup, ctx, graph=False, kernel_
     model_cpu = build_model(cfg)
     state = {k: v.clone() for k, v in model_cpu.state_dict().items()} if keep_state else None
     model = model_cpu.to(dev)
-    engine.set_conv_mode("f32x3" if dtype == "f32x3" else (conv if (dtype == "fp32" and mode == "infer") else "f32"))
+    engine.set_conv_mode("f32x3" if dtype == "f32x3" else (conv if dtype == "fp32" else "f32"))
     if dtype == "bf16":
         model = model.bfloat16()
     seed = replicas.frame_seed(0x5EED, config if mode == "train" else 2, rank)     # inference legs share config 2's images
@@ -394,7 +394,7 @@ def main():
             if mode == "train":
                 ctx["inputs"].drop()
             try:
-                rec, _ = run_leg(config, dtype, mode, batch, args.extra_steps, 2, ctx)
+                rec, _ = run_leg(config, dtype, mode, batch, args.extra_steps, 2, ctx, conv=args.conv)
             except Exception as e:                               # a failed extra never takes the headline with it
                 rec = {"workload": CONFIGS[config]["name"], "dtype": dtype, "error": f"{type(e).__name__}: {e}"[:300]}
             extras.append(rec)
@@ -408,7 +408,7 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": cfg["name"], "batch_per_gpu": args.batch,
                        "parallelism": f"replicas x{world}" if args.mode == "infer" else f"dp{world}",
-                       "conv_kernels": args.conv if args.dtype == "fp32" and args.mode == "infer" else "f32",
+                       "conv_kernels": args.conv if args.dtype == "fp32" else "f32",
                        "weights": "random-init (synthetic, seeded)", "launch": "hipGraph replay" if args.graph else "eager",
                        "mode": head["mode"]},
             # ranks of the process group the barrier / MAX (and, in training legs, the gradient all-reduce) ran on

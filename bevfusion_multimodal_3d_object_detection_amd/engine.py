@@ -48,14 +48,16 @@ class PackedConv:
     wino: bool = False       # w is the transformed-filter image of the fused Winograd kernel (csrc/conv_wino.hip)
 
 
-_CONV_MODE = "f32"
+_CONV_MODE = "wino"
 
 
 def set_conv_mode(mode: str) -> None:
-    """How fp32 models multiply in their convolutions.  "f32" (default): v_mfma_f32_32x32x2_f32, an exact fp32 FMA
-    chain.  "wino": the 3x3 / stride 1 / pad 1 layers (Cin % 32 == 0) run as fused fp32 Winograd F(2x2,3x3) on
-    v_mfma_f32_16x16x4_f32 (csrc/conv_wino.hip: fp32 products and accumulation, 2.25x fewer of them, a few 1e-7
-    relative from the direct kernel); every other layer as "f32".  "f32x3": opt-in, fp32 operands split exactly into three bf16 planes and multiplied on the bf16 MFMA
+    """How fp32 models multiply in their convolutions.  "wino" (default): the 3x3 / stride 1 / pad 1 layers
+    (Cin % 32 == 0; ~85 % of the path's FLOPs) run as fused fp32 Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32
+    (csrc/conv_wino.hip: fp32 products and accumulation, 2.25x fewer of them; a few 1e-7 relative from the direct
+    kernel per layer, the whole detector within 1e-4 of the oracle at full size -- tests/test_gpu_wino.py), every other
+    layer as "f32".  "f32": v_mfma_f32_32x32x2_f32 everywhere, an exact fp32 FMA chain whose bits do not depend on
+    tile shapes.  "f32x3": opt-in, fp32 operands split exactly into three bf16 planes and multiplied on the bf16 MFMA
     (six partial products, fp32 accumulate; csrc/conv_split.hip) -- fp32-level error, ~1.3-1.4x faster, not
     bit-identical to the default.  Engines repack on the next forward."""
     global _CONV_MODE
@@ -68,7 +70,7 @@ def conv_mode() -> str:
     return _CONV_MODE
 
 
-def pack_conv(conv, bn=None, relu: bool = True, split_ok: bool = True) -> PackedConv:
+def pack_conv(conv, bn=None, relu: bool = True, split_ok: bool = True, wino_ok: bool = True) -> PackedConv:
     """Weights keep the module's storage dtype (fp32 or bf16); the folded BN scale/shift are always fp32.
     In "f32x3" mode fp32 filters with Cin % 32 == 0 are stored as three bf16 planes (split_ok=False: layers whose
     launch needs what the f32x3 kernel lacks, i.e. the fused column max)."""
@@ -81,13 +83,13 @@ def pack_conv(conv, bn=None, relu: bool = True, split_ok: bool = True) -> Packed
     pad = conv.padding[0] if isinstance(conv.padding, tuple) else conv.padding
     scale, shift = _bn_fold(conv.bias, bn, cout, w.device)
     packed = w.permute(0, 2, 3, 1).contiguous().view(-1)
-    return _finish_pack(packed, scale, shift, cin, cout, kh, stride, pad, relu, split_ok)
+    return _finish_pack(packed, scale, shift, cin, cout, kh, stride, pad, relu, split_ok, wino_ok)
 
 
-def _finish_pack(packed, scale, shift, cin, cout, k, stride, pad, relu, split_ok=True) -> PackedConv:
+def _finish_pack(packed, scale, shift, cin, cout, k, stride, pad, relu, split_ok=True, wino_ok=True) -> PackedConv:
     """OHWI filter -> what the active conv mode's kernel reads."""
     if packed.dtype == torch.float32 and cin % 32 == 0:
-        if _CONV_MODE == "wino" and (k, stride, pad) == (3, 1, 1):
+        if _CONV_MODE == "wino" and wino_ok and (k, stride, pad) == (3, 1, 1):
             return PackedConv(L.wino_filter_transform(packed, cout, cin), scale, shift, cin, cout, k, stride, pad, relu, wino=True)
         if _CONV_MODE == "f32x3" and split_ok:
             packed = L.split_weights_f32x3(packed)
@@ -442,8 +444,10 @@ class FusionEngine(_Engine):
         if m.use_radar:
             r0 = m.radar_proj[0]
             self.rp = (r0.weight.detach().contiguous(), r0.bias.detach().float().contiguous())
-            self.rr1 = pack_conv(m.radar_refine[0], m.radar_refine[1], True)
-            self.rr2 = pack_conv(m.radar_refine[3], m.radar_refine[4], True)
+            # exact kernel whatever the mode: the 5x5 border-class shortcut below must reproduce the full-map convolution
+            # bit for bit, which a position-dependent Winograd tiling would not (and these two launches cost nothing)
+            self.rr1 = pack_conv(m.radar_refine[0], m.radar_refine[1], True, wino_ok=False)
+            self.rr2 = pack_conv(m.radar_refine[3], m.radar_refine[4], True, wino_ok=False)
         self.f1 = pack_conv(m.bev_fusion[0], m.bev_fusion[1], True)
         self.f2 = pack_conv(m.bev_fusion[3], m.bev_fusion[4], True)
 

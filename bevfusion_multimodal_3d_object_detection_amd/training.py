@@ -92,22 +92,31 @@ def _image_chunk(N: int, *per_image_elems: int) -> int:
     return N if N <= n_max else -(-N // -(-N // n_max))
 
 
+def _wino_ok(cin, k, stride, pad) -> bool:
+    """The fused fp32 Winograd kernel (csrc/conv_wino.hip) serves the 3x3 / stride 1 / pad 1 layers when the conv mode
+    says so (engine.set_conv_mode("wino")): forward and data-gradient convolutions of the training step alike."""
+    return E.conv_mode() == "wino" and (k, stride, pad) == (3, 1, 1) and cin % 32 == 0
+
+
+def _conv_launch(x, w_ohwi, bias, y, n, H, W, cin, cout, k, stride, pad, relu, res=None):
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    if _wino_ok(cin, k, stride, pad):
+        with E._span("conv_wino_f32", flops=2.0 * n * Ho * Wo * cout * k * k * cin):
+            L.conv3x3_wino(x, L.wino_filter_transform(w_ohwi, cout, cin), None, bias, y, N=n, H=H, W=W, Cin=cin, x_cs=cin,
+                           Cout=cout, y_cs=cout, relu=relu, res=res, res_cs=cout if res is not None else 0)
+        return
+    with E._span("conv_igemm_f32", flops=2.0 * n * Ho * Wo * cout * k * k * cin):
+        L.conv2d_nhwc(x, w_ohwi, None, bias, y, N=n, H=H, W=W, Cin=cin, x_cs=cin, Cout=cout, y_cs=cout, KH=k, KW=k,
+                      stride=stride, pad=pad, relu=relu, res=res, res_cs=cout if res is not None else 0)
+
+
 def conv_raw(x, w_ohwi, bias, N, H, W, cin, cout, k, stride, pad, relu=False):
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     per = _image_chunk(N, H * W * cin, Ho * Wo * cout)
-    if per < N:
-        y = _new(N * Ho * Wo * cout, x.device)
-        for i0 in range(0, N, per):
-            n = min(per, N - i0)
-            with E._span("conv_igemm_f32", flops=2.0 * n * Ho * Wo * cout * k * k * cin):
-                L.conv2d_nhwc(x[i0 * H * W * cin:], w_ohwi, None, bias, y[i0 * Ho * Wo * cout:], N=n, H=H, W=W, Cin=cin, x_cs=cin,
-                              Cout=cout, y_cs=cout, KH=k, KW=k, stride=stride, pad=pad, relu=relu)
-        return y, Ho, Wo
-    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     y = _new(N * Ho * Wo * cout, x.device)
-    with E._span("conv_igemm_f32", flops=2.0 * N * Ho * Wo * cout * k * k * cin):
-        L.conv2d_nhwc(x, w_ohwi, None, bias, y, N=N, H=H, W=W, Cin=cin, x_cs=cin, Cout=cout, y_cs=cout, KH=k, KW=k,
-                      stride=stride, pad=pad, relu=relu)
+    for i0 in range(0, N, per):
+        n = min(per, N - i0)
+        _conv_launch(x[i0 * H * W * cin:], w_ohwi, bias, y[i0 * Ho * Wo * cout:], n, H, W, cin, cout, k, stride, pad, relu)
     return y, Ho, Wo
 
 
@@ -189,9 +198,13 @@ def conv_dgrad(dy, weight_oihw, N, H, W, cin, cout, k, stride, pad, add=None):
         assert (Ho, Wo) == (H, W), "stride-1 convs on this path keep the spatial size"
     dx = _new(N * H * W * cin, dy.device)
     with E._span("conv_dgrad_f32", flops=flops):
-        L.conv2d_nhwc(src, wt, None, None, dx, N=N, H=sh, W=sw, Cin=cout, x_cs=cout, Cout=cin, y_cs=cin, KH=k, KW=k,
-                      stride=1, pad=k - 1 - pad, relu=False, res=add if stride == 1 else None,
-                      res_cs=cin if (add is not None and stride == 1) else 0)
+        if stride == 1 and _wino_ok(cout, k, 1, k - 1 - pad):
+            L.conv3x3_wino(src, L.wino_filter_transform(wt, cin, cout), None, None, dx, N=N, H=sh, W=sw, Cin=cout, x_cs=cout,
+                           Cout=cin, y_cs=cin, relu=False, res=add, res_cs=cin if add is not None else 0)
+        else:
+            L.conv2d_nhwc(src, wt, None, None, dx, N=N, H=sh, W=sw, Cin=cout, x_cs=cout, Cout=cin, y_cs=cin, KH=k, KW=k,
+                          stride=1, pad=k - 1 - pad, relu=False, res=add if stride == 1 else None,
+                          res_cs=cin if (add is not None and stride == 1) else 0)
     if add is not None and stride != 1:
         add_(dx, add, min(dx.numel(), add.numel()))
     return dx

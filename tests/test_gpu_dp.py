@@ -91,5 +91,11 @@ def test_two_ranks_on_one_gpu_match_the_mean_gradient_step(gpu):
         assert rel_err(a, ref.cpu()) <= 1e-5                      # float-atomic accumulation order differs run to run
     opt = training.FusedAdamW(model.parameters(), lr=1e-3, weight_decay=0.01, max_grad_norm=10.0)
     opt.step()
-    for a, p in zip(p0, list(model.parameters())[:6]):
-        assert rel_err(a, p.detach().cpu()) <= 1e-5
+    # the first AdamW step moves every element by ~lr * sign(g): where |g| is rounding noise (e.g. a convolution bias in
+    # front of a train-mode BatchNorm) the sign, hence the element, legitimately differs between two runs whose
+    # float-atomic accumulation order differs -- compare the elements whose gradient is well above that noise
+    for a, p, ref in zip(p0, list(model.parameters())[:6], [(x + y) / 2 for x, y in zip(ga[:6], gb[:6])]):
+        solid = (ref.abs() > 1e-3 * ref.abs().max()).cpu()
+        assert float(solid.float().mean()) > 0.5
+        assert rel_err(a[solid], p.detach().cpu()[solid]) <= 1e-5
+        assert float((a - p.detach().cpu()).abs().max()) <= 2.1e-3               # nowhere more than two steps of lr 1e-3 apart

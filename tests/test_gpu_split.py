@@ -72,14 +72,17 @@ def test_detector_in_f32x3_mode_matches_oracle_like_fp32(gpu):
     with torch.no_grad():
         ref = ora(imgs, pts, None)
     m = m.cuda().eval()
-    exact = {k: v.clone() for k, v in m(imgs.cuda(), pts.cuda(), None).items()}
-    engine.set_conv_mode("f32x3")
+    default = engine.conv_mode()
+    engine.set_conv_mode("f32")
     try:
+        exact = {k: v.clone() for k, v in m(imgs.cuda(), pts.cuda(), None).items()}
+        engine.set_conv_mode("f32x3")
         split = {k: v.clone() for k, v in m(imgs.cuda(), pts.cuda(), None).items()}
         assert m.camera_encoder._engine.blocks[0][0].w.dtype == torch.bfloat16        # really repacked as planes
-    finally:
         engine.set_conv_mode("f32")
-    again = m(imgs.cuda(), pts.cuda(), None)
+        again = m(imgs.cuda(), pts.cuda(), None)
+    finally:
+        engine.set_conv_mode(default)
     for k in ref:
         assert rel_err(split[k].cpu(), ref[k]) <= 1e-4, k
         assert rel_err(split[k].cpu(), exact[k].cpu()) <= 2e-5, k

@@ -18,9 +18,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture()
 def wino_mode():
+    before = engine.conv_mode()
     engine.set_conv_mode("wino")
     yield
-    engine.set_conv_mode("f32")
+    engine.set_conv_mode(before)
 
 
 def _nhwc(t):

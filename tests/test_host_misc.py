@@ -19,7 +19,8 @@ def test_image_chunks_are_balanced_and_respect_the_limit(monkeypatch):
 
 
 def test_conv_mode_switch_validates_and_changes_engine_signature():
-    assert engine.conv_mode() == "f32"
+    default = engine.conv_mode()
+    assert default == "wino"                     # fused fp32 Winograd for the 3x3 / stride 1 layers
     with pytest.raises(ValueError):
         engine.set_conv_mode("bf16x9")
     m = fusion.create_detector("camera_only", "bev", "centernet", bev_h=16, bev_w=16)
@@ -29,7 +30,7 @@ def test_conv_mode_switch_validates_and_changes_engine_signature():
     try:
         assert eng._signature() != before                                         # next forward repacks
     finally:
-        engine.set_conv_mode("f32")
+        engine.set_conv_mode(default)
     assert eng._signature() == before
 
 
