@@ -228,48 +228,61 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
       const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res), 0, (int)kOob, 0x00020000);
       const unsigned y_lane = (unsigned)((((n * p.H + oy) * p.W + ox) * p.y_cs + ct * 64 + t) * 4);
       const unsigned r_lane = (unsigned)((((n * p.H + oy) * p.W + ox) * p.res_cs + ct * 64 + t) * 4);
+      // interior tile blocks (all 16x16 pixels and all 64 channels exist): no per-element predicate at all; the scalar
+      // part of every address is an SGPR offset.  Edge blocks: out-of-range elements get an out-of-range VGPR offset.
+      auto emit = [&](auto interiorc) {
+        constexpr bool kInt = decltype(interiorc)::value;
+        float sc[4], sh[4];
+        bool cok[4];
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb) {
-        __builtin_amdgcn_sched_barrier(0);
-        const int co = ct * 64 + nb * 16 + t;
-        const bool cok = co < p.Cout;
-        const float sc = (p.scale && cok) ? p.scale[co] : 1.f;
-        const float sh = (p.shift && cok) ? p.shift[co] : 0.f;
-        unsigned voy[16];
-        float rv[16];
+        for (int nb = 0; nb < 4; ++nb) {
+          const int co = ct * 64 + nb * 16 + t;
+          cok[nb] = kInt || co < p.Cout;
+          sc[nb] = (p.scale && cok[nb]) ? p.scale[co] : 1.f;
+          sh[nb] = (p.shift && cok[nb]) ? p.shift[co] : 0.f;
+        }
+        auto live = [&](int nb, int q) {                             // q = r*4 + i*2 + j
+          return kInt || (cok[nb] && oy + ((q >> 1) & 1) < p.H && ox + 2 * (q >> 2) + (q & 1) < p.W);
+        };
+        float rv[4][16];
+        if constexpr (RES) {                                         // all 64 residual loads first: one latency, hidden under
+#pragma unroll                                                       // the accumulator reads and output transforms below
+          for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {                             // q = r*4 + i*2 + j
-          const int r = q >> 2, i = (q >> 1) & 1, j = q & 1;
-          const bool ok = interior || (cok && oy + i < p.H && ox + 2 * r + j < p.W);
-          voy[q] = ok ? y_lane : kOob;
-          if constexpr (RES)
-            rv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                        rsr, ok ? r_lane : kOob, (unsigned)(((i * p.W + 2 * r + j) * p.res_cs + nb * 16) * 4), 0));
+            for (int q = 0; q < 16; ++q)
+              rv[nb][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                              rsr, live(nb, q) ? r_lane : kOob,
+                              (unsigned)(((((q >> 1) & 1) * p.W + 2 * (q >> 2) + (q & 1)) * p.res_cs + nb * 16) * 4), 0));
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float s[2][4];
+        for (int nb = 0; nb < 4; ++nb) {
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int nu = 0; nu < 4; ++nu) {
-            const float m0 = acc[0 + nu][nb][r], m1 = acc[4 + nu][nb][r], m2 = acc[8 + nu][nb][r], m3 = acc[12 + nu][nb][r];
-            s[0][nu] = m0 + m1 + m2;
-            s[1][nu] = m1 - m2 - m3;
-          }
+          for (int r = 0; r < 4; ++r) {
+            float s[2][4];
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const float yv[2] = {s[i][0] + s[i][1] + s[i][2], s[i][1] - s[i][2] - s[i][3]};
+            for (int nu = 0; nu < 4; ++nu) {
+              const float m0 = acc[0 + nu][nb][r], m1 = acc[4 + nu][nb][r], m2 = acc[8 + nu][nb][r], m3 = acc[12 + nu][nb][r];
+              s[0][nu] = m0 + m1 + m2;
+              s[1][nu] = m1 - m2 - m3;
+            }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              const int q = r * 4 + i * 2 + j;
-              float o = fmaf(yv[j], sc, sh);
-              if constexpr (RES) o += rv[q];
-              if constexpr (RELU) o = fmaxf(o, 0.f);
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rsy, voy[q],
-                                                    (unsigned)(((i * p.W + 2 * r + j) * p.y_cs + nb * 16) * 4), 0);
+            for (int i = 0; i < 2; ++i) {
+              const float yv[2] = {s[i][0] + s[i][1] + s[i][2], s[i][1] - s[i][2] - s[i][3]};
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                const int q = r * 4 + i * 2 + j;
+                float o = fmaf(yv[j], sc[nb], sh[nb]);
+                if constexpr (RES) o += rv[nb][q];
+                if constexpr (RELU) o = fmaxf(o, 0.f);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rsy, live(nb, q) ? y_lane : kOob,
+                                                      (unsigned)(((i * p.W + 2 * r + j) * p.y_cs + nb * 16) * 4), 0);
+              }
             }
           }
         }
-      }
+      };
+      if (interior) emit(std::true_type{}); else emit(std::false_type{});
     }
   }
 }
