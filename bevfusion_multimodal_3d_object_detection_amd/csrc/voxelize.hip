@@ -7,14 +7,14 @@
 //   * a voxel keeps its first max_points points in input order, zero padded.
 // Pipeline (all frames of the batch at once):
 //   keys  (frame, cell, point index) packed in 64 bits                          -- one thread per point
-//   sort  device radix sort of the keys (rocPRIM/hipCUB primitive)               -- groups cells, keeps order
+//   sort  per frame, one workgroup: stable LSD radix sort on the cell bits, 8 bits a pass; an element's rank inside
+//         its wave comes from 8 ballots (the lanes holding the same digit) + a popcount, the waves' counts are
+//         prefix-summed per digit in LDS                                          -- groups cells, keeps point order
 //   heads a sorted position is a segment head when its (frame,cell) differs from its predecessor; the head
 //         marks its first point in a per-point flag array                         -- one thread per position
 //   scan  per-frame exclusive scan of the flags in POINT order = voxel id in first-appearance order
 //   fill  one wave per voxel copies its first max_points points with 16-byte-free, coalesced row copies
 #include "common.h"
-
-#include <hipcub/hipcub.hpp>
 
 namespace {
 
@@ -43,6 +43,86 @@ __global__ __launch_bounds__(256) void vox_keys(const VoxArgs a, unsigned long l
     cell = ((unsigned long long)(int)fz * a.gy + (int)fy) * a.gx + (int)fx;
   // frame in the top bits so one sort serves the whole batch; invalid points sort to the end of their frame
   keys[i] = ((unsigned long long)b << 52) | (cell << 20) | (unsigned long long)n;
+}
+
+// Stable LSD radix sort of one frame's keys by cell (bits 20..51), 8 bits per pass, `passes` passes; the point index in
+// the low 20 bits is already ascending in the input, and a stable sort keeps it so.  One workgroup of 1024 threads
+// (16 waves) per frame walks the frame in tiles of 1024 keys IN ORDER:
+//   * rank inside the wave: 8 ballots narrow the lane mask down to the lanes holding the same digit; the number of
+//     those below the lane is its rank, the lowest of them publishes the count for (wave, digit);
+//   * 256 threads turn the 16 per-wave counts of each digit into offsets and advance the digit's running base;
+//   * every key is written to base[digit] + earlier waves of the tile + rank in the wave.
+// Ends with the sorted keys in `a` when `passes` is even, in `b` when odd.
+__global__ __launch_bounds__(1024) void vox_sort(unsigned long long* __restrict__ a, unsigned long long* __restrict__ b, int N,
+                                                  int passes) {
+  __shared__ int hist[4][256];
+  __shared__ int base[256];
+  __shared__ int wcnt[16][256];
+  __shared__ int wtot[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned long long* src = a + (size_t)blockIdx.x * N;
+  unsigned long long* dst = b + (size_t)blockIdx.x * N;
+  hist[tid >> 8][tid & 255] = 0;
+  __syncthreads();
+  for (int i = tid; i < N; i += 1024) {
+    const unsigned cell = (unsigned)(src[i] >> 20);
+    for (int q = 0; q < passes; ++q) atomicAdd(&hist[q][(cell >> (8 * q)) & 255], 1);
+  }
+  __syncthreads();
+  for (int q = 0; q < passes; ++q) {
+    if (tid < 256) {                                            // exclusive scan of the 256 digit counts -> base
+      const int c = hist[q][tid];
+      int incl = c;
+#pragma unroll
+      for (int s = 1; s < 64; s <<= 1) {
+        const int up = __shfl_up(incl, s);
+        if (lane >= s) incl += up;
+      }
+      if (lane == 63) wtot[wave] = incl;
+      base[tid] = incl - c;                                     // within the wave for now
+    }
+    __syncthreads();
+    if (tid < 256) {
+      int off = 0;
+      for (int w = 0; w < wave; ++w) off += wtot[w];
+      base[tid] += off;
+    }
+    __syncthreads();
+    for (int tile0 = 0; tile0 < N; tile0 += 1024) {
+      for (int e = tid; e < 16 * 256; e += 1024) (&wcnt[0][0])[e] = 0;
+      __syncthreads();
+      const int i = tile0 + tid;
+      const bool valid = i < N;
+      const unsigned long long key = valid ? src[i] : 0ull;
+      const unsigned d = ((unsigned)(key >> 20) >> (8 * q)) & 255u;
+      unsigned long long peers = __ballot(valid);
+#pragma unroll
+      for (int bit = 0; bit < 8; ++bit) {
+        const bool set = (d >> bit) & 1u;
+        const unsigned long long bb = __ballot(set);
+        peers &= set ? bb : ~bb;
+      }
+      const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+      if (valid && rank == 0) wcnt[wave][d] = __popcll(peers);
+      __syncthreads();
+      if (tid < 256) {
+        int run = base[tid];
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+          const int c = wcnt[w][tid];
+          wcnt[w][tid] = run;
+          run += c;
+        }
+        base[tid] = run;
+      }
+      __syncthreads();
+      if (valid) dst[wcnt[wave][d] + rank] = key;
+      __syncthreads();
+    }
+    unsigned long long* t = src; src = dst; dst = t;
+    __threadfence_block();
+    __syncthreads();
+  }
 }
 
 // head_flag[b][n] = sorted position + 1 of the segment whose first point is n (0 elsewhere)
@@ -130,18 +210,11 @@ __global__ __launch_bounds__(256) void vox_fill(const VoxArgs a, const unsigned 
   }
 }
 
-size_t sort_temp_bytes(long long n) {
-  size_t bytes = 0;
-  (void)hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, (const unsigned long long*)nullptr,
-                                          (unsigned long long*)nullptr, (int)n, 0, 64);
-  return bytes;
-}
-
 }  // namespace
 
 extern "C" size_t bevf_voxelize_work_bytes(int B, int N) {
   const long long n = (long long)B * N;
-  return (size_t)n * 16 + (size_t)n * 8 + sort_temp_bytes(n) + 256;      // keys in/out, head_flag + vid, sort scratch
+  return (size_t)n * 16 + (size_t)n * 8 + 256;                           // keys (two buffers), head_flag + vid
 }
 
 extern "C" int bevf_voxelize_f32(const bevf_voxelize_desc* d, void* stream) {
@@ -167,13 +240,15 @@ extern "C" int bevf_voxelize_f32(const bevf_voxelize_desc* d, void* stream) {
   unsigned long long* keys = keys_in + n;
   int* head_flag = reinterpret_cast<int*>(keys + n);
   int* vid = head_flag + n;
-  void* temp = vid + n;
-  size_t temp_bytes = sort_temp_bytes(n);
   const unsigned grid = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(vox_keys, dim3(grid), dim3(256), 0, st, a, keys_in);
-  // frame (12 bits) | cell (32 bits) | point (20 bits): sort all 64 bits
-  hipError_t e = hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, keys_in, keys, (int)n, 0, 64, st);
-  if (e != hipSuccess) { bevf_set_error("voxelize: radix sort failed: %s", hipGetErrorString(e)); return BEVF_ERR_LAUNCH; }
+  // frame (12 bits) | cell (32 bits) | point (20 bits).  Frames are independent: each is sorted by one workgroup on as many
+  // 8-bit digits as the grid's cell count needs (the invalid cell, all ones, then still sorts behind every valid cell)
+  const unsigned long long ncells = (unsigned long long)a.gx * a.gy * a.gz;
+  int passes = 1;
+  while (passes < 4 && (1ull << (8 * passes)) <= ncells) ++passes;
+  hipLaunchKernelGGL(vox_sort, dim3(d->B), dim3(1024), 0, st, keys_in, keys, d->N, passes);
+  if ((passes & 1) == 0) keys = keys_in;                         // an even number of passes ends in the first buffer
   if (hipMemsetAsync(head_flag, 0, (size_t)n * sizeof(int), st) != hipSuccess) {
     bevf_set_error("voxelize: memset failed");
     return BEVF_ERR_LAUNCH;
