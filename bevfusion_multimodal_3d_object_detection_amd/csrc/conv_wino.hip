@@ -31,6 +31,7 @@ namespace {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define MFMA(acc_, a_, b_) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc_) : "v"(a_), "v"(b_))
+#define MFMA0(acc_, a_, b_) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=a"(acc_) : "v"(a_), "v"(b_))
 
 struct WinoArgs {
   const float* x;      // NHWC, channel stride x_cs
@@ -117,9 +118,12 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
   int tile = blockIdx.x;
   unsigned pv[11], pvl[11];
   int n, by, bx, ct;
-  make_pv(tile, pv, n, by, bx, ct);
+  {                                                                 // filter DMA first: it flies while the slot offsets are computed
+    const int ct0 = tile / nsp;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) dma_piece(ub + (size_t)ct * G * BG_FLOATS, 0, i);
+    for (int i = 0; i < 8; ++i) dma_piece(ub + (size_t)ct0 * G * BG_FLOATS, 0, i);
+  }
+  make_pv(tile, pv, n, by, bx, ct);
   {
     f32x4 r[11];
 #pragma unroll
@@ -140,8 +144,9 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
   // one channel group (8 channels = 2 MFMA k-steps); gl = position in the 32-channel patch chunk (static)
   //   pvl / psoff: where the NEXT chunk's patch comes from (this tile's next chunk, or the next tile's chunk 0)
   //   bsrc: the NEXT group's filter image (null: nothing follows)
-  auto group = [&](auto glc, const unsigned psoff, const float* bsrc) {
+  auto group = [&](auto glc, auto firstc, const unsigned psoff, const float* bsrc) {
     constexpr int gl = decltype(glc)::value;
+    constexpr bool kFirst = decltype(firstc)::value;      // a tile's first group: its k-step-0 MFMAs start the accumulators (C = 0)
     const int abuf = gl == 3 ? pbuf ^ 1 : pbuf;                     // A fragments of the next group: next chunk after gl 3
     constexpr int agl = (gl + 1) & 3;
     f32x4 rr[4];
@@ -160,7 +165,8 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int j = k >> 2, nb = k & 3;
-        MFMA(acc[f][nb], a[j], bc[nb >> 1][(nb & 1) * 2 + j]);
+        if (kFirst && j == 0) MFMA0(acc[f][nb], a[j], bc[nb >> 1][(nb & 1) * 2 + j]);
+        else MFMA(acc[f][nb], a[j], bc[nb >> 1][(nb & 1) * 2 + j]);
         if (k == 0 && f < 15) bn[0] = *reinterpret_cast<const f32x4*>(pb + ((f + 1) * 2) * 256);
         if (k == 1 && f < 15) bn[1] = *reinterpret_cast<const f32x4*>(pb + ((f + 1) * 2 + 1) * 256);
         if (f < 4) {                                                // patch row f of the next group: 4 x b64
@@ -198,10 +204,8 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
   using G3 = std::integral_constant<int, 3>;
 
   {                                                                 // one tile per workgroup
-#pragma unroll
-    for (int f = 0; f < 16; ++f)
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb) acc[f][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    using T = std::true_type;
+    using F = std::false_type;
 #pragma unroll
     for (int i = 0; i < 11; ++i) pvl[i] = pv[i];
     for (int chunk = 0; chunk < NCH; ++chunk) {                     // 32 channels
@@ -212,10 +216,10 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
 #pragma unroll                                                      // zeros without touching memory (the SGPR offset is not range-checked)
         for (int i = 0; i < 11; ++i) pvl[i] = kOob;
       }
-      group(G0{}, soff, ug + 1 * BG_FLOATS);
-      group(G1{}, soff, ug + 2 * BG_FLOATS);
-      group(G2{}, soff, ug + 3 * BG_FLOATS);
-      group(G3{}, soff, lastc ? nullptr : ug + 4 * BG_FLOATS);
+      if (chunk == 0) group(G0{}, T{}, soff, ug + 1 * BG_FLOATS); else group(G0{}, F{}, soff, ug + 1 * BG_FLOATS);
+      group(G1{}, F{}, soff, ug + 2 * BG_FLOATS);
+      group(G2{}, F{}, soff, ug + 3 * BG_FLOATS);
+      group(G3{}, F{}, soff, lastc ? nullptr : ug + 4 * BG_FLOATS);
       pbuf ^= 1;
     }
 
@@ -257,28 +261,27 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
           __builtin_amdgcn_sched_barrier(0);
+          f32x4 sr[2][4];                                            // A^T M over the frequency rows, all four tiles r at once
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float s[2][4];
+          for (int nu = 0; nu < 4; ++nu) {
+            const f32x4 m0 = acc[0 + nu][nb], m1 = acc[4 + nu][nb], m2 = acc[8 + nu][nb], m3 = acc[12 + nu][nb];
+            sr[0][nu] = m0 + m1 + m2;
+            sr[1][nu] = m1 - m2 - m3;
+          }
 #pragma unroll
-            for (int nu = 0; nu < 4; ++nu) {
-              const float m0 = acc[0 + nu][nb][r], m1 = acc[4 + nu][nb][r], m2 = acc[8 + nu][nb][r], m3 = acc[12 + nu][nb][r];
-              s[0][nu] = m0 + m1 + m2;
-              s[1][nu] = m1 - m2 - m3;
-            }
+          for (int i = 0; i < 2; ++i) {
+            const f32x4 yv[2] = {sr[i][0] + sr[i][1] + sr[i][2], sr[i][1] - sr[i][2] - sr[i][3]};
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-              const float yv[2] = {s[i][0] + s[i][1] + s[i][2], s[i][1] - s[i][2] - s[i][3]};
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-              for (int j = 0; j < 2; ++j) {
+              for (int r = 0; r < 4; ++r) {
                 const int q = r * 4 + i * 2 + j;
-                float o = fmaf(yv[j], sc[nb], sh[nb]);
+                float o = fmaf(yv[j][r], sc[nb], sh[nb]);
                 if constexpr (RES) o += rv[nb][q];
                 if constexpr (RELU) o = fmaxf(o, 0.f);
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rsy, live(nb, q) ? y_lane : kOob,
                                                       (unsigned)(((i * p.W + 2 * r + j) * p.y_cs + nb * 16) * 4), 0);
               }
-            }
           }
         }
       };
