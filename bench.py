@@ -139,8 +139,9 @@ def pmc_traffic(config: int, batch: int):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_config{config}_b{batch}.json")
         if os.path.exists(path):
             d = json.load(open(path))
-            n = sum(v["launches"] for k, v in d.items() if k.startswith("conv_igemm"))
-            tot = sum(v["launches"] * v["hbm_bytes_per_launch"] for k, v in d.items() if k.startswith("conv_igemm"))
+            conv = [v for k, v in d.items() if k.startswith(("conv_igemm", "wino_f32"))]
+            n = sum(v["launches"] for v in conv)
+            tot = sum(v["launches"] * v["hbm_bytes_per_launch"] for v in conv)
             if n:
                 return tot / n, "committed profile: " + os.path.relpath(path, ROOT)
     return None
