@@ -25,7 +25,8 @@ class ConvDesc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
                 ("res", C.c_void_p), ("y", C.c_void_p), ("colmax", C.c_void_p)] + \
                [(n, C.c_int32) for n in ("N", "H", "W", "Cin", "x_cs", "Ho", "Wo", "Cout", "y_cs", "res_cs",
-                                         "KH", "KW", "stride", "pad", "relu", "rows_per_group", "tile")]
+                                         "KH", "KW", "stride", "pad", "relu", "rows_per_group", "tile")] + \
+               [("stats", C.c_void_p), ("stats_pivot", C.c_void_p)]
 
 
 class RadarDesc(C.Structure):
@@ -103,6 +104,8 @@ SIGNATURES = {
     "bevf_wino_filter_floats": (C.c_size_t, [C.c_int] * 2),
     "bevf_wino_filter_transform_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 2 + [C.c_void_p]),
     "bevf_conv3x3_wino_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "bevf_wino_stat_rows": (C.c_int, [C.c_int] * 3),
+    "bevf_bn_stats_from_partials_f32": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 2 + [C.c_float, C.c_void_p]),
     "bevf_centernet_decode_work_bytes": (C.c_size_t, [C.c_int] * 5),
     "bevf_centernet_decode_f32": (C.c_int, [C.POINTER(DecodeDesc), C.c_void_p]),
     "bevf_centernet_targets_f32": (C.c_int, [C.POINTER(TargetsDesc), C.c_void_p]),
@@ -256,8 +259,14 @@ def wino_filter_transform(w_ohwi: torch.Tensor, Cout: int, Cin: int) -> torch.Te
 
 
 def conv3x3_wino(x: torch.Tensor, u: torch.Tensor, scale, shift, y: torch.Tensor, *, N: int, H: int, W: int, Cin: int,
-                 x_cs: int, Cout: int, y_cs: int, relu: bool, res: Optional[torch.Tensor] = None, res_cs: int = 0) -> None:
-    """3x3 / stride 1 / pad 1 convolution as fused fp32 Winograd F(2x2,3x3); `u` from wino_filter_transform."""
+                 x_cs: int, Cout: int, y_cs: int, relu: bool, res: Optional[torch.Tensor] = None, res_cs: int = 0,
+                 stats: Optional[torch.Tensor] = None, stats_pivot: Optional[torch.Tensor] = None) -> None:
+    """3x3 / stride 1 / pad 1 convolution as fused fp32 Winograd F(2x2,3x3); `u` from wino_filter_transform.
+    `stats` [bevf_wino_stat_rows(N,H,W)][Cout][2]: also leave the BatchNorm partial sums of the output (training)."""
+    if stats is not None and stats.numel() < lib().bevf_wino_stat_rows(N, H, W) * Cout * 2:
+        raise BevfError("conv_wino: stats buffer too small")
+    if stats_pivot is not None and stats_pivot.numel() < Cout:
+        raise BevfError("conv_wino: stats_pivot shorter than Cout")
     M = N * H * W
     if x.numel() < (M - 1) * x_cs + Cin:
         raise BevfError("conv_wino: input buffer smaller than N*H*W*x_cs")
@@ -271,7 +280,7 @@ def conv3x3_wino(x: torch.Tensor, u: torch.Tensor, scale, shift, y: torch.Tensor
         if v is not None and v.numel() != Cout:
             raise BevfError("conv_wino: scale/shift length != Cout")
     d = ConvDesc(_p(x), _pc(u), _pc(scale), _pc(shift), _p(res), _p(y), None, N, H, W, Cin, x_cs, H, W, Cout, y_cs, res_cs,
-                 3, 3, 1, 1, int(relu), 0, 0)
+                 3, 3, 1, 1, int(relu), 0, 0, _p(stats), _pc(stats_pivot))
     _check(lib().bevf_conv3x3_wino_f32(C.byref(d), _stream()), "bevf_conv3x3_wino_f32")
 
 

@@ -40,6 +40,8 @@ struct WinoArgs {
   const float* shift;
   const float* res;    // NHWC residual or null
   float* y;
+  float* stats;        // STATS: [nsp * 4][Cout][2] partial sums of (y - pivot), (y - pivot)^2
+  const float* pivot;  // [Cout] or null
   int N, H, W, Cin, x_cs, Cout, y_cs, res_cs;
   int TBY, TBX, nct;   // tile blocks per image (rows, cols), 64-channel slabs
 };
@@ -49,7 +51,7 @@ constexpr int PATCH_FLOATS = PIX * PITCH;                      // 11664 floats =
 constexpr int BG_FLOATS = 16 * 4 * 16 * 8;                     // 8192 floats = 32 KB per channel group
 constexpr int LDS_BYTES = (2 * PATCH_FLOATS + 2 * BG_FLOATS) * 4;
 
-template <bool RES, bool RELU>
+template <bool RES, bool RELU, bool STATS = false>
 __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const patch = lds;                                     // [2][PIX][PITCH]
@@ -261,6 +263,8 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
           __builtin_amdgcn_sched_barrier(0);
+          float st1 = 0.f, st2 = 0.f;                                // STATS: this lane's sums for channel nb*16 + t
+          const float pvt = (STATS && p.pivot && cok[nb]) ? p.pivot[ct * 64 + nb * 16 + t] : 0.f;
           f32x4 sr[2][4];                                            // A^T M over the frequency rows, all four tiles r at once
 #pragma unroll
           for (int nu = 0; nu < 4; ++nu) {
@@ -281,7 +285,21 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
                 if constexpr (RELU) o = fmaxf(o, 0.f);
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rsy, live(nb, q) ? y_lane : kOob,
                                                       (unsigned)(((i * p.W + 2 * r + j) * p.y_cs + nb * 16) * 4), 0);
+                if constexpr (STATS) {
+                  const float dv = live(nb, q) ? o - pvt : 0.f;
+                  st1 += dv;
+                  st2 = fmaf(dv, dv, st2);
+                }
               }
+          }
+          if constexpr (STATS) {                                    // the four lane groups kq hold the same channel: fixed xor tree
+            st1 += __shfl_xor(st1, 16); st2 += __shfl_xor(st2, 16);
+            st1 += __shfl_xor(st1, 32); st2 += __shfl_xor(st2, 32);
+            if (kq == 0 && cok[nb]) {
+              float* dst = p.stats + (((size_t)(tile - ct * nsp) * 4 + wave) * p.Cout + ct * 64 + nb * 16 + t) * 2;
+              dst[0] = st1;
+              dst[1] = st2;
+            }
           }
         }
       };
@@ -322,6 +340,8 @@ __global__ __launch_bounds__(256) void wino_filter_transform(const float* __rest
 
 }  // namespace
 
+extern "C" int bevf_wino_stat_rows(int N, int H, int W) { return N * ((H + 15) / 16) * ((W + 15) / 16) * 4; }
+
 extern "C" size_t bevf_wino_filter_floats(int Cout, int Cin) {
   return (size_t)((Cout + 63) / 64) * 64 * 16 * (size_t)Cin;
 }
@@ -351,6 +371,8 @@ extern "C" int bevf_conv3x3_wino_f32(const bevf_conv_desc* d, void* stream) {
                "conv_wino: activations must stay below 2 GiB (32-bit buffer offsets)");
   WinoArgs a;
   a.x = d->x; a.u = d->w; a.scale = d->scale; a.shift = d->shift; a.res = d->res; a.y = d->y;
+  a.stats = d->stats; a.pivot = d->stats_pivot;
+  BEVF_REQUIRE(!d->stats || (!d->res && !d->relu), "conv_wino: stats need relu = 0 and no residual (they describe the raw conv output)");
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.x_cs = d->x_cs; a.Cout = d->Cout; a.y_cs = d->y_cs; a.res_cs = d->res_cs;
   a.TBY = (d->H + 15) / 16; a.TBX = (d->W + 15) / 16; a.nct = (d->Cout + 63) / 64;
   const long long ntiles = (long long)d->N * a.TBY * a.TBX * a.nct;
@@ -362,9 +384,14 @@ extern "C" int bevf_conv3x3_wino_f32(const bevf_conv_desc* d, void* stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_f32<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_f32<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_f32<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_f32<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_done = true;
   }
   const dim3 grid((unsigned)ntiles), block(256);
+  if (d->stats) {
+    hipLaunchKernelGGL((wino_f32<false, false, true>), grid, block, LDS_BYTES, st, a);
+    return bevf_check_launch("bevf_conv3x3_wino_f32");
+  }
   if (d->res) {
     if (d->relu) hipLaunchKernelGGL((wino_f32<true, true>), grid, block, LDS_BYTES, st, a);
     else hipLaunchKernelGGL((wino_f32<true, false>), grid, block, LDS_BYTES, st, a);

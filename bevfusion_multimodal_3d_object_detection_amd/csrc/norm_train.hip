@@ -396,6 +396,16 @@ extern "C" int bevf_bn_stats_f32(const float* x, float* work, float* mean, float
   return bevf_check_launch("bevf_bn_stats_f32");
 }
 
+// Batch statistics from partial sums a producer left behind (bevf_conv3x3_wino_f32 with `stats`): part [G][C][2] =
+// {sum(x - pivot), sum((x - pivot)^2)} over disjoint row sets covering all M rows.  Same fixed-order double merge as above.
+extern "C" int bevf_bn_stats_from_partials_f32(const float* part, int G, const float* pivot, float* mean, float* var,
+                                               float* invstd, int M, int C, float eps, void* stream) {
+  BEVF_REQUIRE(part && pivot && mean && var && invstd && G > 0 && M > 0 && C > 0, "bn_stats_from_partials: bad arguments");
+  hipLaunchKernelGGL(stats_finalize, dim3((C + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), pivot, part, mean, var,
+                     invstd, M, C, G, eps);
+  return bevf_check_launch("bevf_bn_stats_from_partials_f32");
+}
+
 extern "C" int bevf_bn_update_running_f32(const float* mean, const float* var, float* running_mean, float* running_var,
                                           int64_t* num_batches_tracked, int C, int M, float momentum, void* stream) {
   BEVF_REQUIRE(mean && var && running_mean && running_var && C > 0 && M > 0, "bn_update_running: bad arguments");

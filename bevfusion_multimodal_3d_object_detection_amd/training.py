@@ -98,25 +98,41 @@ def _wino_ok(cin, k, stride, pad) -> bool:
     return E.conv_mode() == "wino" and (k, stride, pad) == (3, 1, 1) and cin % 32 == 0
 
 
-def _conv_launch(x, w_ohwi, bias, y, n, H, W, cin, cout, k, stride, pad, relu, res=None):
+def _conv_launch(x, w_ohwi, bias, y, n, H, W, cin, cout, k, stride, pad, relu, res=None, stats=None):
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     if _wino_ok(cin, k, stride, pad):
         with E._span("conv_wino_f32", flops=2.0 * n * Ho * Wo * cout * k * k * cin):
             L.conv3x3_wino(x, L.wino_filter_transform(w_ohwi, cout, cin), None, bias, y, N=n, H=H, W=W, Cin=cin, x_cs=cin,
-                           Cout=cout, y_cs=cout, relu=relu, res=res, res_cs=cout if res is not None else 0)
+                           Cout=cout, y_cs=cout, relu=relu, res=res, res_cs=cout if res is not None else 0,
+                           stats=stats[0] if stats else None, stats_pivot=stats[1] if stats else None)
         return
     with E._span("conv_igemm_f32", flops=2.0 * n * Ho * Wo * cout * k * k * cin):
         L.conv2d_nhwc(x, w_ohwi, None, bias, y, N=n, H=H, W=W, Cin=cin, x_cs=cin, Cout=cout, y_cs=cout, KH=k, KW=k,
                       stride=stride, pad=pad, relu=relu, res=res, res_cs=cout if res is not None else 0)
 
 
-def conv_raw(x, w_ohwi, bias, N, H, W, cin, cout, k, stride, pad, relu=False):
+def conv_raw(x, w_ohwi, bias, N, H, W, cin, cout, k, stride, pad, relu=False, bn_pivot=None):
+    """y = conv(x) (+bias) (+ReLU).  bn_pivot [cout] (training forward in front of a BatchNorm, Winograd layers only): the
+    conv epilogue also leaves the BatchNorm partial sums; returns (y, Ho, Wo, partials or None) then, partials =
+    (part [G][cout][2], G, pivot) for bn_train_forward."""
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     per = _image_chunk(N, H * W * cin, Ho * Wo * cout)
     y = _new(N * Ho * Wo * cout, x.device)
+    fuse = bn_pivot is not None and not relu and _wino_ok(cin, k, stride, pad)
+    part, rows = None, 0
+    if fuse:
+        rows_of = lambda n: _lib().bevf_wino_stat_rows(n, H, W)
+        G = sum(rows_of(min(per, N - i0)) for i0 in range(0, N, per))
+        part = _new(G * cout * 2, x.device)
     for i0 in range(0, N, per):
         n = min(per, N - i0)
-        _conv_launch(x[i0 * H * W * cin:], w_ohwi, bias, y[i0 * Ho * Wo * cout:], n, H, W, cin, cout, k, stride, pad, relu)
+        st = None
+        if fuse:
+            st = (part[rows * cout * 2:], bn_pivot)
+            rows += rows_of(n)
+        _conv_launch(x[i0 * H * W * cin:], w_ohwi, bias, y[i0 * Ho * Wo * cout:], n, H, W, cin, cout, k, stride, pad, relu, stats=st)
+    if bn_pivot is not None:
+        return y, Ho, Wo, ((part, rows, bn_pivot) if fuse else None)
     return y, Ho, Wo
 
 
@@ -214,13 +230,27 @@ class _BNState:
     __slots__ = ("mean", "invstd", "xraw", "y", "M", "C", "has_res")
 
 
-def bn_train_forward(xraw, bn: nn.BatchNorm2d, M: int, Cc: int, res=None, relu=True, apply=True):
-    """Batch statistics (+ running-buffer update) and, unless apply=False, the normalised activation."""
+def bn_pivot_of(bn) -> Optional[torch.Tensor]:
+    """Shift for the BatchNorm partial sums a conv epilogue produces: any value near the channel mean avoids cancellation
+    in E[(x-p)^2] - E[x-p]^2; the running mean is at hand (None: the layer keeps none, the sums stay separate)."""
+    rm = getattr(bn, "running_mean", None)
+    return rm.detach() if (rm is not None and rm.dtype == torch.float32 and rm.is_cuda) else None
+
+
+def bn_train_forward(xraw, bn: nn.BatchNorm2d, M: int, Cc: int, res=None, relu=True, apply=True, partials=None):
+    """Batch statistics (+ running-buffer update) and, unless apply=False, the normalised activation.
+    partials = (part, G, pivot) from a conv epilogue: the statistics are merged from them, xraw is not re-read."""
     dev = xraw.device
-    work = _new(_lib().bevf_bn_work_floats(Cc), dev)
     mean, var, invstd = _new(Cc, dev), _new(Cc, dev), _new(Cc, dev)
-    _ck(_lib().bevf_bn_stats_f32(xraw.data_ptr(), work.data_ptr(), mean.data_ptr(), var.data_ptr(), invstd.data_ptr(),
-                                 M, Cc, Cc, float(bn.eps), _st()), "bevf_bn_stats_f32")
+    if partials is not None:
+        part, G, pivot = partials
+        pivot = pivot.clone()                    # the running mean is updated below, in place
+        _ck(_lib().bevf_bn_stats_from_partials_f32(part.data_ptr(), G, pivot.data_ptr(), mean.data_ptr(), var.data_ptr(),
+                                                   invstd.data_ptr(), M, Cc, float(bn.eps), _st()), "bevf_bn_stats_from_partials_f32")
+    else:
+        work = _new(_lib().bevf_bn_work_floats(Cc), dev)
+        _ck(_lib().bevf_bn_stats_f32(xraw.data_ptr(), work.data_ptr(), mean.data_ptr(), var.data_ptr(), invstd.data_ptr(),
+                                     M, Cc, Cc, float(bn.eps), _st()), "bevf_bn_stats_f32")
     y = None
     if apply:
         y = _new(M * Cc, dev)
@@ -337,9 +367,13 @@ class ConvBNLayer:
             y, Ho, Wo = conv_raw(x, w_ohwi, bias, N, H, W, self.cin, self.cout, self.k, self.stride, self.pad, relu=self.relu)
             self.y, self.M = y, N * Ho * Wo
             return y, Ho, Wo
-        xraw, Ho, Wo = conv_raw(x, w_ohwi, bias, N, H, W, self.cin, self.cout, self.k, self.stride, self.pad)
+        pivot, partials = bn_pivot_of(self.bn), None
+        if pivot is not None:
+            xraw, Ho, Wo, partials = conv_raw(x, w_ohwi, bias, N, H, W, self.cin, self.cout, self.k, self.stride, self.pad, bn_pivot=pivot)
+        else:
+            xraw, Ho, Wo = conv_raw(x, w_ohwi, bias, N, H, W, self.cin, self.cout, self.k, self.stride, self.pad)
         self.M = N * Ho * Wo
-        y, self.bns = bn_train_forward(xraw, self.bn, self.M, self.cout, res=res, relu=self.relu)
+        y, self.bns = bn_train_forward(xraw, self.bn, self.M, self.cout, res=res, relu=self.relu, partials=partials)
         self.has_res = res is not None
         return y, Ho, Wo
 

@@ -64,6 +64,12 @@ typedef struct {
   int32_t rows_per_group;  /* colmax grouping (points per batch element)                     */
   int32_t tile;            /* 0: auto (cost model); 1 128x128, 2 256x64, 3 128x64, 4 64x64, 5-7 hybrid
                               big + 64x64 tail of 1 / 2 / 3 -- forced variants for bench / tests     */
+  /* bevf_conv3x3_wino_f32 only (training forward, ref train-mode nn.BatchNorm2d after the conv): when `stats` is set the
+   * epilogue also leaves per-(tile block, wave) partial sums of the stored outputs, {sum(y - pivot), sum((y - pivot)^2)}
+   * per channel, as rows [bevf_wino_stat_rows(N,H,W)][Cout][2] for bevf_bn_stats_from_partials_f32 -- the BatchNorm
+   * batch statistics without re-reading the activation.  Needs relu = 0 and res = NULL. */
+  float* stats;
+  const float* stats_pivot; /* [Cout] any value near the channel mean (e.g. the running mean); NULL = 0 */
 } bevf_conv_desc;
 int bevf_conv2d_nhwc_f32(const bevf_conv_desc* d, void* stream);
 
@@ -77,6 +83,7 @@ int bevf_conv2d_nhwc_f32(const bevf_conv_desc* d, void* stream);
 size_t bevf_wino_filter_floats(int Cout, int Cin);
 int bevf_wino_filter_transform_f32(const float* w_ohwi, float* u, int Cout, int Cin, void* stream);
 int bevf_conv3x3_wino_f32(const bevf_conv_desc* d, void* stream);
+int bevf_wino_stat_rows(int N, int H, int W);   /* rows of the `stats` partial buffer */
 
 /* ResNet stem: 7x7 stride-2 pad-3 conv on a planar 3-channel image + BN (+ ReLU when relu != 0),
  * ref src/encoders.py:154-156 (torchvision conv1/bn1/relu).  x: [N][3][H][W] (NCHW, as the
@@ -337,6 +344,10 @@ int bevf_bn_update_running_f32(const float* mean, const float* var, float* runni
                                int64_t* num_batches_tracked, int C, int M, float momentum, void* stream);
 int bevf_bn_stats_f32(const float* x, float* work, float* mean, float* var, float* invstd, int M, int C, int cs,
                       float eps, void* stream);
+/* The same statistics from partial sums a producer left behind (bevf_conv3x3_wino_f32 with `stats`): part [G][C][2] =
+ * {sum(x - pivot), sum((x - pivot)^2)} over disjoint row sets covering all M rows; fixed-order merge in double. */
+int bevf_bn_stats_from_partials_f32(const float* part, int G, const float* pivot, float* mean, float* var, float* invstd,
+                                    int M, int C, float eps, void* stream);
 int bevf_bn_apply_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                       const float* res, float* y, int M, int C, int cs, int relu, void* stream);
 /* relu with y == NULL: the mask is recomputed from x exactly as bn_apply computed it (gamma, beta as in the forward;

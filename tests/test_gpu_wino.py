@@ -129,3 +129,33 @@ def test_config2_full_size_wino_against_oracle_and_batch_invariance(gpu, wino_mo
     two = m(torch.cat([imgs, imgs]).cuda(), torch.cat([pts, pts]).cuda(), None)
     for k in one:                                                # the tiling is per image: batching changes no bit
         assert torch.equal(two[k][0:1], one[k]) and torch.equal(two[k][1:2], one[k]), k
+
+
+def test_conv_wino_bn_partial_sums(gpu):
+    """Training forward: the Winograd epilogue leaves {sum(y - pivot), sum((y - pivot)^2)} per (tile block, wave, channel);
+    merged by bevf_bn_stats_from_partials_f32 they are the train-mode BatchNorm statistics of the conv output (edge tile
+    blocks, a channel count that is not a multiple of 64, a pivot far from the mean)."""
+    N, H, W, cin, cout = 2, 37, 29, 64, 80
+    x = synth.normal((N, cin, H, W), 71)
+    w = synth.normal((cout, cin, 3, 3), 72, 0, 0.06)
+    bias = synth.normal((cout,), 73, 3.0, 1.0)                       # means well away from zero
+    pivot = synth.normal((cout,), 74, 2.0, 2.0)
+    ref = F.conv2d(x.double(), w.double(), bias.double(), 1, 1)
+    M = N * H * W
+    rows = L.lib().bevf_wino_stat_rows(N, H, W)
+    part = torch.full((rows * cout * 2,), float("nan"), device=gpu)
+    y = torch.empty(M * cout, device=gpu)
+    u = L.wino_filter_transform(_nhwc(w).view(-1).cuda(), cout, cin)
+    L.conv3x3_wino(_nhwc(x).view(-1).cuda(), u, None, bias.cuda(), y, N=N, H=H, W=W, Cin=cin, x_cs=cin, Cout=cout, y_cs=cout,
+                   relu=False, stats=part, stats_pivot=pivot.cuda())
+    assert bool(torch.isfinite(part).all())                          # every (row, channel) slot was written
+    mean, var, invstd = (torch.empty(cout, device=gpu) for _ in range(3))
+    rc = L.lib().bevf_bn_stats_from_partials_f32(part.data_ptr(), rows, pivot.cuda().data_ptr(), mean.data_ptr(), var.data_ptr(),
+                                                 invstd.data_ptr(), M, cout, 1e-5, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    rm, rv = ref.mean(dim=(0, 2, 3)), ref.var(dim=(0, 2, 3), unbiased=False)
+    assert rel_err(mean.cpu(), rm) <= 2e-6 and rel_err(var.cpu(), rv) <= 2e-5
+    assert rel_err(invstd.cpu(), 1.0 / torch.sqrt(rv + 1e-5)) <= 2e-5
+    with pytest.raises(L.BevfError, match="stats need relu = 0"):
+        L.conv3x3_wino(_nhwc(x).view(-1).cuda(), u, None, None, y, N=N, H=H, W=W, Cin=cin, x_cs=cin, Cout=cout, y_cs=cout,
+                       relu=True, stats=part)
