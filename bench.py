@@ -445,86 +445,5 @@ def main():
         dist.destroy_process_group()
 
 
-def main():
-    argv = sys.argv[1:]
-    args = parse_args(argv)
-    launch_ranks_if_needed(args, argv)              # may not return; nothing above this line touches the GPU
-    if os.environ.get("BEVF_BENCH_STUB") == "1":
-        return stub_main(args)
-
-    import torch
-    from bevfusion_multimodal_3d_object_detection_amd import replicas
-    rank, local_rank, world = replicas.rank_world()
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but {world} rank(s) are running")
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    # one process per GPU.  BEVF_DIST_BACKEND=gloo + fewer GPUs than ranks is a control-flow rehearsal only
-    # (ranks then share a device); the driver's runs use the default: RCCL, one GPU per rank.
-    backend = os.environ.get("BEVF_DIST_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    dist = replicas.init(backend, dev)             # RCCL; inference: only the barrier and the MAX of the elapsed time
-    if dist is not None and dist.get_world_size() != args.gpus:
-        raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
-    if args.mode == "train":
-        args.config = 4
-        if args.dtype != "fp32":
-            raise SystemExit("training runs in exact fp32 (the reference has no mixed precision, SURVEY.md 5)")
-    cfg = CONFIGS[args.config]
-    if args.batch is None:
-        args.batch = 2 if args.config == 5 else 8
-    ctx = dict(dev=dev, dist=dist, rank=rank, world=world, inputs=InputCache(dev))
-
-    head, state = run_leg(args.config, args.dtype, args.mode, args.batch, args.steps, args.warmup, ctx,
-                          graph=args.graph, kernel_timer=not args.no_kernel_timer, keep_state=True, conv=args.conv)
-
-    extras = []
-    if args.extras != "none" and not args.graph:
-        plan = [(3, "bf16", "infer", 8), (5, "bf16", "infer", 2), (4, "fp32", "train", 8)]
-        if world > 1 and args.extras == "auto":
-            plan = [(4, "fp32", "train", 8)]
-        plan = [p for p in plan if (p[0], p[1], p[2]) != (args.config, args.dtype, args.mode)]
-        for config, dtype, mode, batch in plan:
-            if mode == "train":
-                ctx["inputs"].drop()
-            try:
-                rec, _ = run_leg(config, dtype, mode, batch, args.extra_steps, 2, ctx, conv=args.conv)
-            except Exception as e:                               # a failed extra never takes the headline with it
-                rec = {"workload": CONFIGS[config]["name"], "dtype": dtype, "error": f"{type(e).__name__}: {e}"[:300]}
-            extras.append(rec)
-
-    if rank == 0:
-        line = {
-            "metric": f"BEV frames/sec (6-cam+LiDAR, {cfg['bev']}x{cfg['bev']} BEV)",
-            "value": head["value"], "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": cfg["name"], "batch_per_gpu": args.batch,
-                       "parallelism": f"replicas x{world}" if args.mode == "infer" else f"dp{world}",
-                       "conv_kernels": args.conv if args.dtype == "fp32" else "f32",
-                       "weights": "random-init (synthetic, seeded)", "launch": "hipGraph replay" if args.graph else "eager",
-                       "mode": head["mode"]},
-            # ranks of the process group the barrier / MAX (and, in training legs, the gradient all-reduce) ran on
-            "rccl_ranks": dist.get_world_size() if (dist is not None and dist.get_backend() == "nccl") else (1 if dist is None else 0),
-            "dist_backend": dist.get_backend() if dist is not None else None,
-        }
-        if args.mode == "train":
-            line["metric"] = "training frames/sec (camera+LiDAR, per-GPU batch 8)"
-        for k in ("roofline", "roofline_bev_pool", "stem_tflops", "grad_allreduce"):
-            if k in head:
-                line[k] = head[k]
-        if world == 1 and not args.no_cpu_baseline and args.mode == "infer":
-            line["cpu_baseline"] = cpu_baseline(cfg, state)
-            line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
-        if extras:
-            line["extra"] = {"configs": extras}
-        print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-
-
 if __name__ == "__main__":
     main()
