@@ -304,7 +304,7 @@ def run_leg(config, dtype, mode, batch, steps, warmup, ctx, graph=False, kernel_
                                "gflop_per_step": conv["flops"] / timer_steps / 1e9,
                                "share_of_step": conv["ms"] / (1e3 * timer_elapsed),
                                "measured_over": "the timed region" if timer_in_region else "2 untimed steps after the timed region"}
-            if wino:
+            if wino and mode == "infer":
                 # `achieved` counts ALGORITHMIC (direct-convolution) FLOPs, as SURVEY.md 8d tabulates them; the Winograd layers
                 # execute 16/36 of theirs, so the matrix pipe's own utilisation is reported beside it
                 ex = executed / (conv["ms"] * 1e-3) / 1e12
