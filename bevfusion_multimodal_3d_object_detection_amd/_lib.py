@@ -114,6 +114,7 @@ SIGNATURES = {
     "bevf_centernet_loss_f32": (C.c_int, [C.POINTER(LossDesc), C.c_void_p]),
     "bevf_voxelize_work_bytes": (C.c_size_t, [C.c_int] * 2),
     "bevf_voxelize_f32": (C.c_int, [C.POINTER(VoxelizeDesc), C.c_void_p]),
+    "bevf_scatter_voxels_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_void_p]),
     # ---- input pipeline ----
     "bevf_resize_normalize_u8": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 5 + [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 2 +
                                  [C.c_int] + [C.POINTER(C.c_float)] * 2 + [C.c_void_p]),
@@ -515,6 +516,19 @@ def centernet_decode_raw(pred: dict, K: int):
     pool_ind = torch.empty(heat.shape[0], K, dtype=torch.int64, device=heat.device)
     boxes, scores, labels, _, _ = centernet_decode(pred, K, -1.0, 1.0, 0.0, 0.0, False, True, pool_ind)
     return boxes, scores, labels, pool_ind
+
+
+def scatter_voxels(features: torch.Tensor, coords: torch.Tensor, grid, num_voxels: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(B,Nv,C) features + (B,Nv,3) int64 (z,y,x) -> dense (B,C,D,H,W); last row wins on duplicates (ref encoders.py:407-410)."""
+    if features.dim() != 3 or coords.shape != (features.shape[0], features.shape[1], 3):
+        raise BevfError("scatter_voxels: features must be (B,Nv,C) and coords (B,Nv,3)")
+    B, Nv, Cc = features.shape
+    D, H, W = (int(g) for g in grid)
+    out = torch.empty(B, Cc, D, H, W, device=features.device)
+    owner = torch.empty(B * D * H * W, dtype=torch.int32, device=features.device)
+    _check(lib().bevf_scatter_voxels_f32(_pc(features), _pc(coords, torch.int64), _pc(num_voxels, torch.int32),
+                                         _p(owner, torch.int32), _p(out), B, Nv, Cc, D, H, W, _stream()), "bevf_scatter_voxels_f32")
+    return out
 
 
 def voxelize(points: torch.Tensor, pc_range, voxel_size, max_points: int, max_voxels: int):

@@ -210,6 +210,34 @@ __global__ __launch_bounds__(256) void vox_fill(const VoxArgs a, const unsigned 
   }
 }
 
+// ---- dense scatter of per-voxel features into the (D,H,W) grid: ref src/encoders.py:399-410 ---------------------------------
+// `feature_grid[b, :, c0, c1, c2] = features.T`: rows are written in order, so when several rows name one cell the LAST
+// one wins.  Pass 1 records the highest row index per cell (integer atomicMax: order-free), pass 2 writes each cell
+// from its owner (or zeros) -- coalesced along the cells for every channel.
+__global__ __launch_bounds__(256) void scatter_owner(const long long* __restrict__ coords, const int* __restrict__ num_voxels,
+                                                      int* __restrict__ owner, int B, int Nv, int D, int H, int W) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= (long long)B * Nv) return;
+  const int b = (int)(i / Nv), v = (int)(i - (long long)b * Nv);
+  if (num_voxels && v >= num_voxels[b]) return;
+  const long long* c = coords + i * 3;
+  const long long z = c[0], y = c[1], x = c[2];
+  if (z < 0 || z >= D || y < 0 || y >= H || x < 0 || x >= W) return;
+  atomicMax(&owner[(size_t)b * D * H * W + ((size_t)z * H + y) * W + x], v);
+}
+
+__global__ __launch_bounds__(256) void scatter_write(const float* __restrict__ feats, const int* __restrict__ owner,
+                                                      float* __restrict__ out, int B, int Nv, int C, long long cells) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= (long long)B * cells) return;
+  const int b = (int)(i / cells);
+  const long long cell = i - (long long)b * cells;
+  const int v = owner[i];
+  const float* f = v >= 0 ? feats + ((size_t)b * Nv + v) * C : nullptr;
+  float* o = out + (size_t)b * C * cells + cell;
+  for (int c = 0; c < C; ++c) o[(size_t)c * cells] = f ? f[c] : 0.f;
+}
+
 }  // namespace
 
 extern "C" size_t bevf_voxelize_work_bytes(int B, int N) {
@@ -258,4 +286,22 @@ extern "C" int bevf_voxelize_f32(const bevf_voxelize_desc* d, void* stream) {
   hipLaunchKernelGGL(vox_fill, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, st, a, keys, head_flag, vid,
                      d->voxel_features, (long long*)d->voxel_coords, d->num_points);
   return bevf_check_launch("bevf_voxelize_f32");
+}
+
+extern "C" int bevf_scatter_voxels_f32(const float* features, const int64_t* coords, const int32_t* num_voxels, int32_t* owner,
+                                       float* out, int B, int Nv, int C, int D, int H, int W, void* stream) {
+  BEVF_REQUIRE(features && coords && owner && out, "scatter_voxels: null pointer");
+  BEVF_REQUIRE(B > 0 && Nv > 0 && C > 0 && D > 0 && H > 0 && W > 0, "scatter_voxels: empty shape");
+  const long long cells = (long long)D * H * W;
+  BEVF_REQUIRE((long long)B * cells < (1ll << 31) && (long long)B * Nv < (1ll << 31), "scatter_voxels: grid too large");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(owner, 0xFF, (size_t)B * cells * sizeof(int), st) != hipSuccess) {       // -1: no voxel names the cell
+    bevf_set_error("scatter_voxels: memset failed");
+    return BEVF_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(scatter_owner, dim3((unsigned)(((long long)B * Nv + 255) / 256)), dim3(256), 0, st,
+                     reinterpret_cast<const long long*>(coords), num_voxels, owner, B, Nv, D, H, W);
+  hipLaunchKernelGGL(scatter_write, dim3((unsigned)((B * cells + 255) / 256)), dim3(256), 0, st, features, owner, out, B, Nv, C,
+                     cells);
+  return bevf_check_launch("bevf_scatter_voxels_f32");
 }

@@ -286,6 +286,17 @@ def voxelize(points: torch.Tensor, point_cloud_range=(-51.2, -51.2, -5.0, 51.2, 
     return L.voxelize(points.float().contiguous(), point_cloud_range, voxel_size, max_points_per_voxel, max_voxels)
 
 
+def scatter_voxels(voxel_features: torch.Tensor, voxel_coords: torch.Tensor, voxel_grid_shape,
+                   num_voxels: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The dense scatter of `VoxelNetLiDAREncoder.forward` (ref src/encoders.py:399-410) as a kernel: per-voxel features
+    (B,Nv,C) at voxel_coords (B,Nv,3) = (z,y,x) -> (B,C,D,H,W), last row wins where rows collide, zeros elsewhere.  With
+    `num_voxels` (from `voxelize`) the zero-padded rows stay out; without it every row is written, as the reference does.
+    `voxelize` -> `VFELayer` -> `scatter_voxels(..., (1,50,50))[:, :, 0]` is the pillar canvas (B,C,50,50) of the config's grid."""
+    E.require_cuda(voxel_features, voxel_coords)
+    nv = None if num_voxels is None else num_voxels.to(torch.int32).contiguous()
+    return L.scatter_voxels(voxel_features.float().contiguous(), voxel_coords.to(torch.int64).contiguous(), voxel_grid_shape, nv)
+
+
 class VFELayer(nn.Module):
     """ref src/encoders.py:420-455 -- Linear -> BN1d over all B*Nv*P rows -> ReLU -> max over the P points
     of each voxel ("PointNet pillar reduction").  (B,Nv,P,C) -> (B,Nv,out_channels)."""

@@ -266,6 +266,14 @@ typedef struct {
 size_t bevf_voxelize_work_bytes(int B, int N);
 int bevf_voxelize_f32(const bevf_voxelize_desc* d, void* stream);
 
+/* Dense scatter of per-voxel features [B][Nv][C] into out [B][C][D][H][W] at voxel_coords (z,y,x) -- the pillar -> BEV
+ * canvas step, ref src/encoders.py:399-410 (`feature_grid[b, :, c0, c1, c2] = features.T`, rows in order: when several
+ * rows name one cell the LAST one wins; cells no row names are zero).  num_voxels [B] or NULL: with it only rows
+ * v < num_voxels[b] take part (the padding rows of bevf_voxelize_f32 stay out); NULL = every row, exactly like the
+ * reference.  owner: scratch of B*D*H*W int32.  Rows with coordinates outside the grid are ignored. */
+int bevf_scatter_voxels_f32(const float* features, const int64_t* coords, const int32_t* num_voxels, int32_t* owner,
+                            float* out, int B, int Nv, int C, int D, int H, int W, void* stream);
+
 /* ==========================================================================================
  * bf16 storage, fp32 accumulate (BASELINE configs 3 and 5).  Same layouts and geometry as the fp32 entry
  * points, element type bfloat16 wherever a pointer is typed void*: the convolution runs on

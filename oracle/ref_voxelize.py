@@ -38,3 +38,19 @@ def hard_voxelize(points: torch.Tensor, pc_range, voxel_size, max_points: int, m
                 npts[b, v] += 1
         nvox[b] = min(len(table), max_voxels)
     return torch.from_numpy(feats), torch.from_numpy(coords), torch.from_numpy(npts), torch.from_numpy(nvox)
+
+
+def dense_scatter(features: torch.Tensor, coords: torch.Tensor, grid, num_voxels=None) -> torch.Tensor:
+    """ref src/encoders.py:399-410 -- `feature_grid[b, :, c0, c1, c2] = features.T`, written row by row so that the last
+    row naming a cell wins (the reference's advanced-index assignment leaves the order of duplicates unspecified; its
+    sequential reading is what the kernel pins).  num_voxels: only rows below it take part (not in the reference)."""
+    B, Nv, C = features.shape
+    D, H, W = grid
+    out = torch.zeros(B, C, D, H, W)
+    for b in range(B):
+        n = Nv if num_voxels is None else int(num_voxels[b])
+        for v in range(n):
+            z, y, x = (int(t) for t in coords[b, v])
+            if 0 <= z < D and 0 <= y < H and 0 <= x < W:
+                out[b, :, z, y, x] = features[b, v]
+    return out

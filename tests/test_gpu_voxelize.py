@@ -42,3 +42,28 @@ def test_voxelize_empty_and_feeds_vfe(gpu):
     with torch.no_grad():
         ref = ora.eval()(fr)
     assert float((out.cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+def test_scatter_voxels_last_row_wins_and_pillar_canvas(gpu):
+    """Pillar -> BEV canvas (VERDICT r1 missing #5): the dense scatter of ref src/encoders.py:399-410.  Rows colliding in a
+    cell: the last one wins, as sequential assignment does; with num_voxels the padding rows of `voxelize` stay out."""
+    B, Nv, C = 2, 300, 32
+    feats = synth.normal((B, Nv, C), 91)
+    coords = torch.stack([synth.randint((B, Nv), 92, 0, 3), synth.randint((B, Nv), 93, -1, 9), synth.randint((B, Nv), 94, 0, 12)], 2)
+    out = encoders.scatter_voxels(feats.cuda(), coords.cuda(), (2, 8, 11))               # some rows fall outside the grid
+    ref = ref_voxelize.dense_scatter(feats, coords, (2, 8, 11))
+    assert torch.equal(out.cpu(), ref)
+    nv = torch.tensor([250, 17], dtype=torch.int32)
+    out = encoders.scatter_voxels(feats.cuda(), coords.cuda(), (2, 8, 11), nv.cuda())
+    assert torch.equal(out.cpu(), ref_voxelize.dense_scatter(feats, coords, (2, 8, 11), nv))
+    # the whole K20 front end: points -> pillars -> VFELayer -> (B,C,50,50) canvas
+    _, pts, _ = synth.frame_inputs(2, 0, 0, 0, 6000, 4, seed=7)
+    f, c, n, v = encoders.voxelize(pts.cuda(), RANGE, (2.048, 2.048, 8.0), 16, 2500)
+    vfe = encoders.VFELayer(4, 64)
+    synth.fill_state_dict_(vfe, 9)
+    pf = vfe.cuda().eval()(f)
+    canvas = encoders.scatter_voxels(pf, c, (1, 50, 50), v)[:, :, 0]
+    assert tuple(canvas.shape) == (2, 64, 50, 50)
+    assert torch.equal(canvas.cpu(), ref_voxelize.dense_scatter(pf.cpu(), c.cpu(), (1, 50, 50), v.cpu())[:, :, 0])
+    occupied = (canvas.abs().sum(1) > 0).sum(dim=(1, 2)).cpu()
+    assert torch.all(occupied <= v.cpu()) and int(occupied.min()) > 1000                 # uniform points fill most of 2500 pillars

@@ -60,3 +60,18 @@ def test_new_entry_points_refuse_cpu_tensors():
         preprocess.filter_pad_lidar(torch.zeros(10, 4))
     with pytest.raises(L.BevfError):
         preprocess.preprocess_camera_images(torch.zeros(1, 8, 8, 3))                          # not uint8
+
+
+def test_oracle_dense_scatter_is_the_references_index_assignment():
+    """oracle/ref_voxelize.dense_scatter against the statement it restates (ref src/encoders.py:407-410,
+    `feature_grid[b, :, c0, c1, c2] = features.T`) on unique coordinates, where that statement is well defined."""
+    from oracle import ref_voxelize
+    B, C, D, H, W = 2, 5, 2, 6, 7
+    perm = torch.stack([torch.randperm(D * H * W, generator=torch.Generator().manual_seed(b))[:40] for b in range(B)])
+    coords = torch.stack([perm // (H * W), (perm // W) % H, perm % W], dim=2)
+    feats = synth.normal((B, 40, C), 12)
+    grid = torch.zeros(B, C, D, H, W)
+    for b in range(B):
+        c = coords[b].long()
+        grid[b, :, c[:, 0], c[:, 1], c[:, 2]] = feats[b].T
+    assert torch.equal(ref_voxelize.dense_scatter(feats, coords, (D, H, W)), grid)
