@@ -26,7 +26,8 @@ class ConvDesc(C.Structure):
                 ("res", C.c_void_p), ("y", C.c_void_p), ("colmax", C.c_void_p)] + \
                [(n, C.c_int32) for n in ("N", "H", "W", "Cin", "x_cs", "Ho", "Wo", "Cout", "y_cs", "res_cs",
                                          "KH", "KW", "stride", "pad", "relu", "rows_per_group", "tile")] + \
-               [("stats", C.c_void_p), ("stats_pivot", C.c_void_p)]
+               [(n, C.c_void_p) for n in ("stats", "stats_pivot", "bnb_x", "bnb_y", "bnb_mean", "bnb_invstd", "bnb_gamma",
+                                          "bnb_beta")]
 
 
 class RadarDesc(C.Structure):
@@ -105,6 +106,7 @@ SIGNATURES = {
     "bevf_wino_filter_transform_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 2 + [C.c_void_p]),
     "bevf_conv3x3_wino_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "bevf_wino_stat_rows": (C.c_int, [C.c_int] * 3),
+    "bevf_bn_backward_from_partials_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
     "bevf_bn_stats_from_partials_f32": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 2 + [C.c_float, C.c_void_p]),
     "bevf_centernet_decode_work_bytes": (C.c_size_t, [C.c_int] * 5),
     "bevf_centernet_decode_f32": (C.c_int, [C.POINTER(DecodeDesc), C.c_void_p]),
@@ -261,7 +263,7 @@ def wino_filter_transform(w_ohwi: torch.Tensor, Cout: int, Cin: int) -> torch.Te
 
 def conv3x3_wino(x: torch.Tensor, u: torch.Tensor, scale, shift, y: torch.Tensor, *, N: int, H: int, W: int, Cin: int,
                  x_cs: int, Cout: int, y_cs: int, relu: bool, res: Optional[torch.Tensor] = None, res_cs: int = 0,
-                 stats: Optional[torch.Tensor] = None, stats_pivot: Optional[torch.Tensor] = None) -> None:
+                 stats: Optional[torch.Tensor] = None, stats_pivot: Optional[torch.Tensor] = None, bnb: Optional[dict] = None) -> None:
     """3x3 / stride 1 / pad 1 convolution as fused fp32 Winograd F(2x2,3x3); `u` from wino_filter_transform.
     `stats` [bevf_wino_stat_rows(N,H,W)][Cout][2]: also leave the BatchNorm partial sums of the output (training)."""
     if stats is not None and stats.numel() < lib().bevf_wino_stat_rows(N, H, W) * Cout * 2:
@@ -282,6 +284,15 @@ def conv3x3_wino(x: torch.Tensor, u: torch.Tensor, scale, shift, y: torch.Tensor
             raise BevfError("conv_wino: scale/shift length != Cout")
     d = ConvDesc(_p(x), _pc(u), _pc(scale), _pc(shift), _p(res), _p(y), None, N, H, W, Cin, x_cs, H, W, Cout, y_cs, res_cs,
                  3, 3, 1, 1, int(relu), 0, 0, _p(stats), _pc(stats_pivot))
+    if bnb is not None:       # this conv's output is dY of a train-mode BatchNorm(+ReLU) layer: mask + backward sums in the epilogue
+        for k in ("x", "mean", "invstd"):
+            if bnb.get(k) is None:
+                raise BevfError(f"conv_wino: bnb needs '{k}'")
+        if bnb["x"].numel() < M * Cout or (bnb.get("y") is not None and bnb["y"].numel() < M * Cout):
+            raise BevfError("conv_wino: bnb x / y smaller than the output")
+        d.bnb_x, d.bnb_y = _p(bnb["x"]), _p(bnb.get("y"))
+        d.bnb_mean, d.bnb_invstd = _p(bnb["mean"]), _p(bnb["invstd"])
+        d.bnb_gamma, d.bnb_beta = _p(bnb.get("gamma")), _p(bnb.get("beta"))
     _check(lib().bevf_conv3x3_wino_f32(C.byref(d), _stream()), "bevf_conv3x3_wino_f32")
 
 

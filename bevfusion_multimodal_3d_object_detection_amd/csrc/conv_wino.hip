@@ -40,8 +40,13 @@ struct WinoArgs {
   const float* shift;
   const float* res;    // NHWC residual or null
   float* y;
-  float* stats;        // STATS: [nsp * 4][Cout][2] partial sums of (y - pivot), (y - pivot)^2
+  float* stats;        // STATS: [nsp * 4][Cout][2] partial sums of (y - pivot), (y - pivot)^2;  BNB: of dy, dy * xhat
   const float* pivot;  // [Cout] or null
+  // BNB (training backward): this conv's output is the gradient dY of a train-mode BatchNorm(+ReLU) layer; the epilogue applies
+  // that layer's ReLU mask and leaves its backward sums (csrc/norm_train.hip: bn_bwd_partials) -- the layer's own raw
+  // input bnb_x [pixels][Cout], its output bnb_y (mask source when the layer had a residual; else the mask is recomputed
+  // from bnb_x with bn_apply's fma), and its per-channel mean / invstd / gamma / beta
+  const float *bnb_x, *bnb_y, *bnb_mean, *bnb_invstd, *bnb_gamma, *bnb_beta;
   int N, H, W, Cin, x_cs, Cout, y_cs, res_cs;
   int TBY, TBX, nct;   // tile blocks per image (rows, cols), 64-channel slabs
 };
@@ -51,7 +56,7 @@ constexpr int PATCH_FLOATS = PIX * PITCH;                      // 11664 floats =
 constexpr int BG_FLOATS = 16 * 4 * 16 * 8;                     // 8192 floats = 32 KB per channel group
 constexpr int LDS_BYTES = (2 * PATCH_FLOATS + 2 * BG_FLOATS) * 4;
 
-template <bool RES, bool RELU, bool STATS = false>
+template <bool RES, bool RELU, bool STATS = false, int BNB = 0>
 __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const patch = lds;                                     // [2][PIX][PITCH]
@@ -250,21 +255,55 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
         auto live = [&](int nb, int q) {                             // q = r*4 + i*2 + j
           return kInt || (cok[nb] && oy + ((q >> 1) & 1) < p.H && ox + 2 * (q >> 2) + (q & 1) < p.W);
         };
-        float rv[4][16];
-        if constexpr (RES) {                                         // all 64 residual loads first: one latency, hidden under
+        auto soff_of = [&](int nb, int q, int cs) {                  // scalar byte offset of element q of channel block nb
+          return (unsigned)(((((q >> 1) & 1) * p.W + 2 * (q >> 2) + (q & 1)) * cs + nb * 16) * 4);
+        };
+        float rv[BNB ? 2 : 4][16];                                   // residual
+        float lx[BNB ? 2 : 1][16], ly[BNB == 2 ? 2 : 1][16];         // BNB: the BatchNorm layer's raw input / its output
+        const __amdgpu_buffer_rsrc_t rbx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bnb_x), 0, (int)kOob, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rby = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bnb_y), 0, (int)kOob, 0x00020000);
+        auto fetch = [&](int nb, int set) {                          // BNB: one channel block's operands, a block ahead of their use
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const unsigned vo = live(nb, q) ? y_lane : kOob;         // bnb_x / bnb_y are laid out like y (y_cs == Cout)
+            lx[set][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbx, vo, soff_of(nb, q, p.y_cs), 0));
+            if constexpr (BNB == 2)
+              ly[set][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rby, vo, soff_of(nb, q, p.y_cs), 0));
+            if constexpr (RES)
+              rv[set][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                               rsr, live(nb, q) ? r_lane : kOob, soff_of(nb, q, p.res_cs), 0));
+          }
+        };
+        if constexpr (BNB != 0) {
+          fetch(0, 0);
+        } else if constexpr (RES) {                                  // all 64 residual loads first: one latency, hidden under
 #pragma unroll                                                       // the accumulator reads and output transforms below
           for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
             for (int q = 0; q < 16; ++q)
               rv[nb][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                              rsr, live(nb, q) ? r_lane : kOob,
-                              (unsigned)(((((q >> 1) & 1) * p.W + 2 * (q >> 2) + (q & 1)) * p.res_cs + nb * 16) * 4), 0));
+                              rsr, live(nb, q) ? r_lane : kOob, soff_of(nb, q, p.res_cs), 0));
         }
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
           __builtin_amdgcn_sched_barrier(0);
-          float st1 = 0.f, st2 = 0.f;                                // STATS: this lane's sums for channel nb*16 + t
-          const float pvt = (STATS && p.pivot && cok[nb]) ? p.pivot[ct * 64 + nb * 16 + t] : 0.f;
+          if constexpr (BNB != 0) {
+            if (nb < 3) fetch(nb + 1, (nb + 1) & 1);
+          }
+          constexpr int kSets = BNB ? 2 : 4;
+          const int set = nb % kSets;
+          float st1 = 0.f, st2 = 0.f;                                // STATS / BNB: this lane's sums for channel nb*16 + t
+          const int cch = ct * 64 + nb * 16 + t;
+          const float pvt = (STATS && p.pivot && cok[nb]) ? p.pivot[cch] : 0.f;
+          float mu = 0.f, is = 1.f, fa = 1.f, fb = 0.f;
+          if constexpr (BNB != 0) {
+            if (cok[nb]) {
+              mu = p.bnb_mean[cch];
+              is = p.bnb_invstd[cch];
+              fa = (p.bnb_gamma ? p.bnb_gamma[cch] : 1.f) * is;
+              fb = (p.bnb_beta ? p.bnb_beta[cch] : 0.f) - mu * fa;
+            }
+          }
           f32x4 sr[2][4];                                            // A^T M over the frequency rows, all four tiles r at once
 #pragma unroll
           for (int nu = 0; nu < 4; ++nu) {
@@ -281,10 +320,18 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
               for (int r = 0; r < 4; ++r) {
                 const int q = r * 4 + i * 2 + j;
                 float o = fmaf(yv[j][r], sc[nb], sh[nb]);
-                if constexpr (RES) o += rv[nb][q];
+                if constexpr (RES) o += rv[set][q];
                 if constexpr (RELU) o = fmaxf(o, 0.f);
+                if constexpr (BNB != 0) {                             // the consumer's ReLU mask, then its backward sums
+                  const float tv = BNB == 2 ? ly[set][q] : fmaf(lx[set][q], fa, fb);
+                  o = tv > 0.f ? o : 0.f;
+                  if (live(nb, q)) {
+                    st1 += o;
+                    st2 = fmaf(o, (lx[set][q] - mu) * is, st2);
+                  }
+                }
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rsy, live(nb, q) ? y_lane : kOob,
-                                                      (unsigned)(((i * p.W + 2 * r + j) * p.y_cs + nb * 16) * 4), 0);
+                                                      soff_of(nb, q, p.y_cs), 0);
                 if constexpr (STATS) {
                   const float dv = live(nb, q) ? o - pvt : 0.f;
                   st1 += dv;
@@ -292,18 +339,28 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
                 }
               }
           }
-          if constexpr (STATS) {                                    // the four lane groups kq hold the same channel: fixed xor tree
+          if constexpr (STATS || BNB != 0) {                        // the four lane groups kq hold the same channel: fixed xor tree
             st1 += __shfl_xor(st1, 16); st2 += __shfl_xor(st2, 16);
             st1 += __shfl_xor(st1, 32); st2 += __shfl_xor(st2, 32);
-            if (kq == 0 && cok[nb]) {
-              float* dst = p.stats + (((size_t)(tile - ct * nsp) * 4 + wave) * p.Cout + ct * 64 + nb * 16 + t) * 2;
-              dst[0] = st1;
-              dst[1] = st2;
+            if (kq == 0) {                                          // per-wave sums -> LDS (the patch buffers are dead by now)
+              lds[(wave * 64 + nb * 16 + t) * 2] = st1;
+              lds[(wave * 64 + nb * 16 + t) * 2 + 1] = st2;
             }
           }
         }
       };
       if (interior) emit(std::true_type{}); else emit(std::false_type{});
+      if constexpr (STATS || BNB != 0) {                            // one partial row per tile block: the four waves' sums in fixed order
+        __syncthreads();
+        if (tid < 64 && ct * 64 + tid < p.Cout) {
+          float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) { a1 += lds[(w * 64 + tid) * 2]; a2 += lds[(w * 64 + tid) * 2 + 1]; }
+          float* dst = p.stats + ((size_t)(tile - ct * nsp) * p.Cout + ct * 64 + tid) * 2;
+          dst[0] = a1;
+          dst[1] = a2;
+        }
+      }
     }
   }
 }
@@ -340,7 +397,7 @@ __global__ __launch_bounds__(256) void wino_filter_transform(const float* __rest
 
 }  // namespace
 
-extern "C" int bevf_wino_stat_rows(int N, int H, int W) { return N * ((H + 15) / 16) * ((W + 15) / 16) * 4; }
+extern "C" int bevf_wino_stat_rows(int N, int H, int W) { return N * ((H + 15) / 16) * ((W + 15) / 16); }
 
 extern "C" size_t bevf_wino_filter_floats(int Cout, int Cin) {
   return (size_t)((Cout + 63) / 64) * 64 * 16 * (size_t)Cin;
@@ -372,7 +429,14 @@ extern "C" int bevf_conv3x3_wino_f32(const bevf_conv_desc* d, void* stream) {
   WinoArgs a;
   a.x = d->x; a.u = d->w; a.scale = d->scale; a.shift = d->shift; a.res = d->res; a.y = d->y;
   a.stats = d->stats; a.pivot = d->stats_pivot;
-  BEVF_REQUIRE(!d->stats || (!d->res && !d->relu), "conv_wino: stats need relu = 0 and no residual (they describe the raw conv output)");
+  a.bnb_x = d->bnb_x; a.bnb_y = d->bnb_y; a.bnb_mean = d->bnb_mean; a.bnb_invstd = d->bnb_invstd;
+  a.bnb_gamma = d->bnb_gamma; a.bnb_beta = d->bnb_beta;
+  if (d->bnb_x) {
+    BEVF_REQUIRE(d->stats && d->bnb_mean && d->bnb_invstd && !d->relu && !d->stats_pivot && d->y_cs == d->Cout,
+                 "conv_wino: the BatchNorm-backward epilogue needs stats (partials out), mean, invstd, relu = 0 and y_cs == Cout");
+  } else {
+    BEVF_REQUIRE(!d->stats || (!d->res && !d->relu), "conv_wino: stats need relu = 0 and no residual (they describe the raw conv output)");
+  }
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.x_cs = d->x_cs; a.Cout = d->Cout; a.y_cs = d->y_cs; a.res_cs = d->res_cs;
   a.TBY = (d->H + 15) / 16; a.TBX = (d->W + 15) / 16; a.nct = (d->Cout + 63) / 64;
   const long long ntiles = (long long)d->N * a.TBY * a.TBX * a.nct;
@@ -388,6 +452,24 @@ extern "C" int bevf_conv3x3_wino_f32(const bevf_conv_desc* d, void* stream) {
     attr_done = true;
   }
   const dim3 grid((unsigned)ntiles), block(256);
+  if (d->bnb_x) {
+    static bool bnb_attr = false;
+    if (!bnb_attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_f32<false, false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_f32<false, false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_f32<true, false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_f32<true, false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      bnb_attr = true;
+    }
+    if (d->res) {
+      if (d->bnb_y) hipLaunchKernelGGL((wino_f32<true, false, false, 2>), grid, block, LDS_BYTES, st, a);
+      else hipLaunchKernelGGL((wino_f32<true, false, false, 1>), grid, block, LDS_BYTES, st, a);
+    } else {
+      if (d->bnb_y) hipLaunchKernelGGL((wino_f32<false, false, false, 2>), grid, block, LDS_BYTES, st, a);
+      else hipLaunchKernelGGL((wino_f32<false, false, false, 1>), grid, block, LDS_BYTES, st, a);
+    }
+    return bevf_check_launch("bevf_conv3x3_wino_f32");
+  }
   if (d->stats) {
     hipLaunchKernelGGL((wino_f32<false, false, true>), grid, block, LDS_BYTES, st, a);
     return bevf_check_launch("bevf_conv3x3_wino_f32");

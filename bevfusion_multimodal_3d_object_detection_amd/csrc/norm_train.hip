@@ -76,28 +76,33 @@ __global__ __launch_bounds__(256) void stats_partials(const float* __restrict__ 
   }
 }
 
-// merge of the G per-workgroup partials of one channel: one wave per channel, lane l takes g = l, l+64, ... (fixed
-// order), then a fixed xor tree over the 64 lane totals; 4 channels per workgroup
-__device__ __forceinline__ void merge_partials(const float* __restrict__ part, int C, int G, int c, int gl, double& s1,
-                                               double& s2) {
+// merge of the G partial rows of one channel by one 256-thread workgroup: thread l takes g = l, l+256, ... (fixed order), a
+// fixed xor tree merges the 64 lane totals of each wave, and the four wave totals are added in wave order through LDS.
+// Every thread of the workgroup must call it; the result is valid in thread 0.
+__device__ __forceinline__ void merge_partials(const float* __restrict__ part, int C, int G, int c, double& s1, double& s2) {
+  __shared__ double wsum[4][2];
   s1 = 0; s2 = 0;
   if (c < C)
-    for (int g = gl; g < G; g += 64) { s1 += part[((size_t)g * C + c) * 2]; s2 += part[((size_t)g * C + c) * 2 + 1]; }
+    for (int g = threadIdx.x; g < G; g += 256) { s1 += part[((size_t)g * C + c) * 2]; s2 += part[((size_t)g * C + c) * 2 + 1]; }
 #pragma unroll
   for (int sft = 1; sft < 64; sft <<= 1) {
     s1 += __shfl_xor(s1, sft);
     s2 += __shfl_xor(s2, sft);
   }
+  if ((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6][0] = s1; wsum[threadIdx.x >> 6][1] = s2; }
+  __syncthreads();
+  s1 = ((wsum[0][0] + wsum[1][0]) + wsum[2][0]) + wsum[3][0];
+  s2 = ((wsum[0][1] + wsum[1][1]) + wsum[2][1]) + wsum[3][1];
 }
 
 // mean, biased var, invstd from the partials (double, fixed order)
 __global__ __launch_bounds__(256) void stats_finalize(const float* __restrict__ x, const float* __restrict__ part,
                                                        float* __restrict__ mean, float* __restrict__ var,
                                                        float* __restrict__ invstd, int M, int C, int G, float eps) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), gl = threadIdx.x & 63;
+  const int c = blockIdx.x;
   double s1, s2;
-  merge_partials(part, C, G, c, gl, s1, s2);
-  if (c >= C || gl != 0) return;
+  merge_partials(part, C, G, c, s1, s2);
+  if (c >= C || threadIdx.x != 0) return;
   const double sh = x[c], d = s1 / M;
   const double v = s2 / M - d * d;
   mean[c] = (float)(sh + d);
@@ -269,10 +274,10 @@ __global__ __launch_bounds__(256) void bn_bwd_partials(float* __restrict__ dy, c
 
 __global__ __launch_bounds__(256) void sums_finalize(const float* __restrict__ part, float* __restrict__ s_dy,
                                                       float* __restrict__ s_dyx, int C, int G) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), gl = threadIdx.x & 63;
+  const int c = blockIdx.x;
   double s1, s2;
-  merge_partials(part, C, G, c, gl, s1, s2);
-  if (c >= C || gl != 0) return;
+  merge_partials(part, C, G, c, s1, s2);
+  if (c >= C || threadIdx.x != 0) return;
   s_dy[c] = (float)s1;
   if (s_dyx) s_dyx[c] = (float)s2;
 }
@@ -392,7 +397,7 @@ extern "C" int bevf_bn_stats_f32(const float* x, float* work, float* mean, float
   int G = (M + lanes - 1) / lanes;
   if (G > kStatGrid) G = kStatGrid;
   hipLaunchKernelGGL(stats_partials, dim3(G), dim3(256), 256 * 8 * sizeof(float), st, x, work, M, C, cs);
-  hipLaunchKernelGGL(stats_finalize, dim3((C + 3) / 4), dim3(256), 0, st, x, work, mean, var, invstd, M, C, G, eps);
+  hipLaunchKernelGGL(stats_finalize, dim3(C), dim3(256), 0, st, x, work, mean, var, invstd, M, C, G, eps);
   return bevf_check_launch("bevf_bn_stats_f32");
 }
 
@@ -401,7 +406,7 @@ extern "C" int bevf_bn_stats_f32(const float* x, float* work, float* mean, float
 extern "C" int bevf_bn_stats_from_partials_f32(const float* part, int G, const float* pivot, float* mean, float* var,
                                                float* invstd, int M, int C, float eps, void* stream) {
   BEVF_REQUIRE(part && pivot && mean && var && invstd && G > 0 && M > 0 && C > 0, "bn_stats_from_partials: bad arguments");
-  hipLaunchKernelGGL(stats_finalize, dim3((C + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), pivot, part, mean, var,
+  hipLaunchKernelGGL(stats_finalize, dim3(C), dim3(256), 0, static_cast<hipStream_t>(stream), pivot, part, mean, var,
                      invstd, M, C, G, eps);
   return bevf_check_launch("bevf_bn_stats_from_partials_f32");
 }
@@ -441,11 +446,24 @@ extern "C" int bevf_bn_backward_f32(float* dy, const float* y, const float* x, c
   if (G > kStatGrid) G = kStatGrid;
   hipLaunchKernelGGL(bn_bwd_partials, dim3(G), dim3(256), 256 * 8 * sizeof(float), st, dy, y, x, mean, invstd, gamma, beta,
                      work, M, C, cs, relu_mode);
-  hipLaunchKernelGGL(sums_finalize, dim3((C + 3) / 4), dim3(256), 0, st, work, dbeta, dgamma, C, G);
+  hipLaunchKernelGGL(sums_finalize, dim3(C), dim3(256), 0, st, work, dbeta, dgamma, C, G);
   if (dx)
     hipLaunchKernelGGL(bn_bwd_apply, dim3(row_grid(M, C)), dim3(256), 0, st, dy, x, mean, invstd, gamma,
                        dbeta, dgamma, dx, (long long)M, C, cs);
   return bevf_check_launch("bevf_bn_backward_f32");
+}
+
+extern "C" int bevf_bn_backward_from_partials_f32(const float* dy, const float* x, const float* mean, const float* invstd,
+                                                  const float* gamma, const float* part, int G, float* dgamma, float* dbeta,
+                                                  float* dx, int M, int C, int cs, void* stream) {
+  BEVF_REQUIRE(dy && x && mean && invstd && part && dgamma && dbeta, "bn_backward_from_partials: null pointer");
+  BEVF_REQUIRE(G > 0 && M > 0 && C > 0 && C % 4 == 0 && cs >= C && cs % 4 == 0, "bn_backward_from_partials: bad shape");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(sums_finalize, dim3(C), dim3(256), 0, st, part, dbeta, dgamma, C, G);
+  if (dx)
+    hipLaunchKernelGGL(bn_bwd_apply, dim3(row_grid(M, C)), dim3(256), 0, st, dy, x, mean, invstd, gamma, dbeta, dgamma, dx,
+                       (long long)M, C, cs);
+  return bevf_check_launch("bevf_bn_backward_from_partials_f32");
 }
 
 // Backward of y = relu(batchnorm(x)) followed by a max over the P rows of each of B groups (ref src/encoders.py:296-299

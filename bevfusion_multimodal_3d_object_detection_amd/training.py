@@ -165,12 +165,22 @@ def _dgrad_conv(src, filt_oihw_sub, N, Hs, Ws, cin, cout, kh, kw):
     return out, ho, wo
 
 
-def conv_dgrad(dy, weight_oihw, N, H, W, cin, cout, k, stride, pad, add=None):
+def dgrad_can_fuse_bn(N, H, W, cin, cout, k, stride, pad) -> bool:
+    """True when conv_dgrad runs as ONE fused-Winograd launch (so its epilogue can do the next BatchNorm's first backward pass)."""
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    return (stride == 1 and _wino_ok(cout, k, 1, k - 1 - pad) and (Ho, Wo) == (H, W)
+            and _image_chunk(N, H * W * max(cin, cout), (Ho + 1) * (Wo + 1) * cout) >= N)
+
+
+def conv_dgrad(dy, weight_oihw, N, H, W, cin, cout, k, stride, pad, add=None, bnb=None):
     """dX [N*H*W*cin] = conv_transpose(dy, W).  Stride 1: the forward kernel on dy with the flipped filter.  Stride 2
     (3x3 pad 1, or 1x1 pad 0 -- the ResNet shapes): the four input-parity classes (ih&1, iw&1) each see a fixed subset
     of the taps, so each is a small stride-1 conv over dy (1x1 / 1x2 / 2x1 / 2x2 taps) and `interleave2x2` assembles dX:
     exactly the forward's MFMA work instead of 4x on a zero-stuffed grid.  Other strides: zero stuffing.
-    `add` [N*H*W*cin]: a gradient to sum into dX (the skip connection's), fused into the conv epilogue when stride 1."""
+    `add` [N*H*W*cin]: a gradient to sum into dX (the skip connection's), fused into the conv epilogue when stride 1.
+    `bnb` (only with dgrad_can_fuse_bn): dX is the gradient reaching a train-mode BatchNorm(+ReLU) layer described by bnb = dict(x,
+    y|None, mean, invstd, gamma, beta); the epilogue applies that layer's ReLU mask and leaves its backward partial sums:
+    returns (dX_masked, (part, G)) then."""
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     per = _image_chunk(N, H * W * max(cin, cout), (Ho + 1) * (Wo + 1) * cout)
     if per < N or (add is not None and stride != 1):
@@ -215,8 +225,14 @@ def conv_dgrad(dy, weight_oihw, N, H, W, cin, cout, k, stride, pad, add=None):
     dx = _new(N * H * W * cin, dy.device)
     with E._span("conv_dgrad_f32", flops=flops):
         if stride == 1 and _wino_ok(cout, k, 1, k - 1 - pad):
+            part = None
+            if bnb is not None:
+                G = _lib().bevf_wino_stat_rows(N, sh, sw)
+                part = _new(G * cin * 2, dy.device)
             L.conv3x3_wino(src, L.wino_filter_transform(wt, cin, cout), None, None, dx, N=N, H=sh, W=sw, Cin=cout, x_cs=cout,
-                           Cout=cin, y_cs=cin, relu=False, res=add, res_cs=cin if add is not None else 0)
+                           Cout=cin, y_cs=cin, relu=False, res=add, res_cs=cin if add is not None else 0, stats=part, bnb=bnb)
+            if bnb is not None:
+                return dx, (part, G)
         else:
             L.conv2d_nhwc(src, wt, None, None, dx, N=N, H=sh, W=sw, Cin=cout, x_cs=cout, Cout=cin, y_cs=cin, KH=k, KW=k,
                           stride=1, pad=k - 1 - pad, relu=False, res=add if stride == 1 else None,
@@ -292,6 +308,23 @@ def bn_train_backward(dy, s: _BNState, bn, relu=True, need_dx=True):
                                     s.invstd.data_ptr(), g, b, work.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                     dx.data_ptr() if dx is not None else None, s.M, s.C, s.C, int(relu), _st()),
         "bevf_bn_backward_f32")
+    return dx, dgamma[:s.C], dbeta[:s.C]
+
+
+FUSE_BN_BACKWARD = False     # the producing data-gradient conv does the next BatchNorm's first backward pass in its epilogue: correct
+                             # (tests run both settings) but +0.4 ms per step on MI355X, because the Winograd epilogue is exposed time
+
+
+def bn_backward_from_partials(dy, s: _BNState, bn, pre):
+    """BatchNorm backward when the producer of dy already masked it and left the sums as partials: merge + apply."""
+    part, G = pre
+    dev = dy.device
+    dgamma, dbeta = _new(s.C, dev), _new(s.C, dev)
+    dx = _new(s.M * s.C, dev)
+    g = bn.weight.data_ptr() if bn.weight is not None else None
+    _ck(_lib().bevf_bn_backward_from_partials_f32(dy.data_ptr(), s.xraw.data_ptr(), s.mean.data_ptr(), s.invstd.data_ptr(), g,
+                                                  part.data_ptr(), G, dgamma.data_ptr(), dbeta.data_ptr(), dx.data_ptr(),
+                                                  s.M, s.C, s.C, _st()), "bevf_bn_backward_from_partials_f32")
     return dx, dgamma[:s.C], dbeta[:s.C]
 
 
@@ -402,9 +435,22 @@ class ConvBNLayer:
             "bevf_bn_relu_group_max_idx_f32")
         return g, idx
 
-    def backward(self, dy, sink: GradSink, need_dx=True, add=None):
+    def bnb_request(self):
+        """What a producing data-gradient conv needs to do this layer's first BatchNorm-backward pass in its epilogue."""
+        st = self.bns
+        return dict(x=st.xraw, y=st.y if (self.relu and st.has_res) else None, mean=st.mean, invstd=st.invstd,
+                    gamma=self.bn.weight.detach() if self.bn.weight is not None else None,
+                    beta=self.bn.bias.detach() if self.bn.bias is not None else None)
+
+    def can_take_fused_dy(self) -> bool:
+        return self.bn is not None and self.relu and self.cout % 4 == 0
+
+    def backward(self, dy, sink: GradSink, need_dx=True, add=None, fuse_next=None, pre=None):
         """dy: gradient of the layer output (modified in place).  Returns (dx or None, d_res or None); `add` is summed
-        into dx (skip-connection gradient, fused into the data-gradient conv's epilogue when it can be)."""
+        into dx (skip-connection gradient, fused into the data-gradient conv's epilogue when it can be).
+        pre = (part, G): dy arrives with this layer's ReLU mask applied and its BatchNorm-backward sums as partials (the
+        producing conv's epilogue did that pass).  fuse_next: the ConvBNLayer that consumes dx -- when this layer's data
+        gradient is one fused-Winograd launch, its epilogue does THAT layer's pass; the return is then (dx, d_res, pre_next)."""
         d_res = None
         if self.bn is None:
             if self.relu:
@@ -412,11 +458,17 @@ class ConvBNLayer:
                 _ck(_lib().bevf_relu_mask_f32(dy.data_ptr(), self.y.data_ptr(), n4, _st()), "bevf_relu_mask_f32")
             dxraw = dy
         else:
-            dxraw, dgamma, dbeta = bn_train_backward(dy, self.bns, self.bn, relu=self.relu)
+            if pre is not None:
+                dxraw, dgamma, dbeta = bn_backward_from_partials(dy, self.bns, self.bn, pre)
+            else:
+                dxraw, dgamma, dbeta = bn_train_backward(dy, self.bns, self.bn, relu=self.relu)
             sink.add(self.bn.weight, dgamma)
             sink.add(self.bn.bias, dbeta)
             if self.has_res:
                 d_res = dy                                    # masked by the ReLU in place: gradient of the skip input
+        if fuse_next is not None:
+            dx, pre_next = self._conv_backward(dxraw, sink, need_dx, add, fuse_next)
+            return dx, d_res, pre_next
         return self._conv_backward(dxraw, sink, need_dx, add), d_res
 
     def backward_from_groupmax(self, dg, gmax, idx, B: int, P: int, sink: GradSink):
@@ -435,16 +487,23 @@ class ConvBNLayer:
         sink.add(self.bn.bias, dbeta[:self.cout])
         return self._conv_backward(dxraw, sink, True, None)
 
-    def _conv_backward(self, dxraw, sink: GradSink, need_dx=True, add=None):
+    def _conv_backward(self, dxraw, sink: GradSink, need_dx=True, add=None, fuse_next=None):
         if self.conv.bias is not None:
             sink.add(self.conv.bias, colsum(dxraw, self.M, self.cout))
         dw = conv_wgrad(self.x, dxraw, self.N, self.H, self.W, self.cin, self.cout, self.k, self.stride, self.pad)
         w = self.conv.weight
         sink.add(w, dw.permute(0, 3, 1, 2).reshape(w.shape))
-        dx = None
+        dx, pre_next = None, None
         if need_dx:
             w4 = w if w.dim() == 4 else w.unsqueeze(-1)
-            dx = conv_dgrad(dxraw, w4, self.N, self.H, self.W, self.cin, self.cout, self.k, self.stride, self.pad, add=add)
+            geom = (self.N, self.H, self.W, self.cin, self.cout, self.k, self.stride, self.pad)
+            if (fuse_next is not None and FUSE_BN_BACKWARD and fuse_next.can_take_fused_dy() and fuse_next.cout == self.cin
+                    and fuse_next.M == self.N * self.H * self.W and dgrad_can_fuse_bn(*geom)):
+                dx, pre_next = conv_dgrad(dxraw, w4, *geom, add=add, bnb=fuse_next.bnb_request())
+            else:
+                dx = conv_dgrad(dxraw, w4, *geom, add=add)
+        if fuse_next is not None:
+            return dx, pre_next
         return dx
 
 
@@ -549,14 +608,20 @@ class DetectorTape:
     def _camera_backward(self, dfeat, sink):
         enc = self.m.camera_encoder
         d, _ = self.proj.backward(dfeat, sink)
-        for i, (c1, c2, down) in enumerate(reversed(self.blocks)):
-            dt, d_res = c2.backward(d, sink)                   # d_res: gradient reaching the skip connection
+        rev = list(reversed(self.blocks))
+        pre = None                                             # BatchNorm-backward partials that arrive WITH d (or None)
+        for i, (c1, c2, down) in enumerate(rev):
+            # c2's data-gradient conv does the first BatchNorm-backward pass of c1 (mask + sums) in its epilogue
+            dt, d_res, pre1 = c2.backward(d, sink, fuse_next=c1, pre=pre)      # d_res: gradient reaching the skip connection
+            pre = None
             if down is not None:
-                dx, _ = c1.backward(dt, sink)
+                dx, _ = c1.backward(dt, sink, pre=pre1)
                 dd, _ = down.backward(d_res, sink)
                 add_(dx, dd, dx.numel())
+            elif i + 1 < len(rev):                             # identity skip: summed in the dgrad conv's epilogue, which then
+                dx, _, pre = c1.backward(dt, sink, add=d_res, fuse_next=rev[i + 1][1], pre=pre1)   # serves the previous block's c2
             else:
-                dx, _ = c1.backward(dt, sink, add=d_res)       # identity skip: summed in the dgrad conv's epilogue
+                dx, _ = c1.backward(dt, sink, add=d_res, pre=pre1)
             d = dx
             if i % 2 == 1:
                 sink.ready()                                   # one ResNet stage done: its gradients can travel
@@ -844,9 +909,13 @@ class DetectorTape:
         for k, c3 in enumerate(convs3):
             sink.add(c3.weight, dw3[k * self.hc:(k + 1) * self.hc])
             sink.add(c3.bias, db3[k * self.hc:(k + 1) * self.hc])
-        dfused = conv_dgrad(dhid, self.head_w3, B, Sh, Sw, cin, c5, 3, 1, 1)
-        da1, _ = self.f2.backward(dfused, sink)
-        dconcat, _ = self.f1.backward(da1, sink)
+        pre_f2 = None
+        if FUSE_BN_BACKWARD and self.f2.can_take_fused_dy() and dgrad_can_fuse_bn(B, Sh, Sw, cin, c5, 3, 1, 1):
+            dfused, pre_f2 = conv_dgrad(dhid, self.head_w3, B, Sh, Sw, cin, c5, 3, 1, 1, bnb=self.f2.bnb_request())
+        else:
+            dfused = conv_dgrad(dhid, self.head_w3, B, Sh, Sw, cin, c5, 3, 1, 1)
+        da1, _, pre_f1 = self.f2.backward(dfused, sink, fuse_next=self.f1, pre=pre_f2)
+        dconcat, _ = self.f1.backward(da1, sink, pre=pre_f1)
         bc = m.fusion.bev_channels
         if self.has_rad:
             ccs = self.ccs

@@ -65,11 +65,24 @@ typedef struct {
   int32_t tile;            /* 0: auto (cost model); 1 128x128, 2 256x64, 3 128x64, 4 64x64, 5-7 hybrid
                               big + 64x64 tail of 1 / 2 / 3 -- forced variants for bench / tests     */
   /* bevf_conv3x3_wino_f32 only (training forward, ref train-mode nn.BatchNorm2d after the conv): when `stats` is set the
-   * epilogue also leaves per-(tile block, wave) partial sums of the stored outputs, {sum(y - pivot), sum((y - pivot)^2)}
+   * epilogue also leaves per-tile-block partial sums of the stored outputs, {sum(y - pivot), sum((y - pivot)^2)}
    * per channel, as rows [bevf_wino_stat_rows(N,H,W)][Cout][2] for bevf_bn_stats_from_partials_f32 -- the BatchNorm
    * batch statistics without re-reading the activation.  Needs relu = 0 and res = NULL. */
   float* stats;
   const float* stats_pivot; /* [Cout] any value near the channel mean (e.g. the running mean); NULL = 0 */
+  /* bevf_conv3x3_wino_f32 only (training backward): when `bnb_x` is set, this convolution's output (+ res) is the gradient
+   * dY reaching a train-mode BatchNorm(+ReLU) layer, and the epilogue does that layer's first backward pass on the way out
+   * (what bevf_bn_backward_f32 would start with): dY is stored with the layer's ReLU mask applied -- mask from its output
+   * `bnb_y`, or, if NULL (the layer had no residual input), recomputed from its raw input `bnb_x` exactly as the forward did --
+   * and `stats` receives {sum dY, sum dY * xhat} per (tile block, channel) for bevf_bn_backward_from_partials_f32.
+   * bnb_x / bnb_y: [N*H*W][Cout]; bnb_mean, bnb_invstd (required), bnb_gamma, bnb_beta (NULL = 1 / 0): [Cout].
+   * Needs relu = 0, stats_pivot = NULL, y_cs == Cout. */
+  const float* bnb_x;
+  const float* bnb_y;
+  const float* bnb_mean;
+  const float* bnb_invstd;
+  const float* bnb_gamma;
+  const float* bnb_beta;
 } bevf_conv_desc;
 int bevf_conv2d_nhwc_f32(const bevf_conv_desc* d, void* stream);
 
@@ -363,6 +376,12 @@ int bevf_bn_apply_f32(const float* x, const float* mean, const float* invstd, co
 int bevf_bn_backward_f32(float* dy, const float* y, const float* x, const float* mean, const float* invstd,
                          const float* gamma, const float* beta, float* work, float* dgamma, float* dbeta, float* dx,
                          int M, int C, int cs, int relu, void* stream);
+/* The same backward when the producer of dy has already applied the ReLU mask and left the per-channel partial sums
+ * (bevf_conv3x3_wino_f32 with bnb_x): part [G][C][2] = {sum dy, sum dy * xhat}.  Merges them (fixed order, double) into
+ * dbeta / dgamma and writes dx = gamma * invstd * (dy - sum_dy / M - xhat * sum_dyx / M). */
+int bevf_bn_backward_from_partials_f32(const float* dy, const float* x, const float* mean, const float* invstd,
+                                       const float* gamma, const float* part, int G, float* dgamma, float* dbeta, float* dx,
+                                       int M, int C, int cs, void* stream);
 
 int bevf_add_inplace_f32(float* y, const float* x, size_t n, void* stream);            /* y += x            */
 int bevf_relu_mask_f32(float* dy, const float* y, size_t n, void* stream);             /* dy *= (y > 0)     */

@@ -200,6 +200,33 @@ def test_train_step_golden(gpu, opt_name):
     assert int(model.camera_encoder.bn1.num_batches_tracked) == 4
 
 
+def test_bn_backward_fused_into_the_dgrad_epilogue_gives_the_same_gradients(gpu):
+    """training.FUSE_BN_BACKWARD: the fused-Winograd data-gradient conv applies the next BatchNorm's ReLU mask and leaves its
+    backward sums as partials (bevf_conv3x3_wino_f32 with bnb_x, both mask sources, with and without the skip gradient).
+    Off by default (slower on MI355X); it must still produce the gradients of the separate pass."""
+    c, model, imgs, pts, boxes, labels = _train_case()
+    tgt = ct.prepare_centernet_targets({"gt_boxes": boxes, "gt_labels": labels}, gpu)
+    saved = {n: b.clone() for n, b in model.named_buffers()}
+
+    def grads(flag):
+        training.FUSE_BN_BACKWARD = flag
+        for n, b in model.named_buffers():
+            b.copy_(saved[n])                                                 # same BatchNorm buffers for both passes
+        for p in model.parameters():
+            p.grad = None
+        try:
+            ct.CenterNetLoss()(model(imgs, pts, None), tgt)["total_loss"].backward()
+        finally:
+            training.FUSE_BN_BACKWARD = False
+        return {n: p.grad.clone() for n, p in model.named_parameters()}
+
+    sep, fused = grads(False), grads(True)
+    gn = float(torch.sqrt(sum((g.double() ** 2).sum() for g in sep.values())))
+    for n in sep:
+        err = float((sep[n] - fused[n]).abs().max())
+        assert err <= 2e-5 * float(sep[n].abs().max()) + 1e-7 * gn, (n, err)
+
+
 def test_train_steps_do_not_leak_device_memory(gpu):
     """Activations of a step are released when its backward has run (no autograd reference cycle)."""
     import gc
