@@ -246,9 +246,17 @@ class _BNState:
     __slots__ = ("mean", "invstd", "xraw", "y", "M", "C", "has_res")
 
 
+FUSE_BN_STATS = False        # BatchNorm batch statistics from partial sums the Winograd conv epilogue leaves (no stats pass over the
+                             # activation).  Built and tested, but off: time-neutral on MI355X (the epilogue is exposed time), and the
+                             # sums are shifted by the RUNNING mean, so their accuracy depends on how far that is from the batch mean
+                             # (two otherwise identical steps differed by 2e-4 in a gradient when only the running mean differed)
+
+
 def bn_pivot_of(bn) -> Optional[torch.Tensor]:
-    """Shift for the BatchNorm partial sums a conv epilogue produces: any value near the channel mean avoids cancellation
-    in E[(x-p)^2] - E[x-p]^2; the running mean is at hand (None: the layer keeps none, the sums stay separate)."""
+    """Shift for the BatchNorm partial sums a conv epilogue produces (FUSE_BN_STATS): any value near the channel mean avoids
+    cancellation in E[(x-p)^2] - E[x-p]^2; the running mean is at hand (None: the sums stay a separate, self-shifted pass)."""
+    if not FUSE_BN_STATS:
+        return None
     rm = getattr(bn, "running_mean", None)
     return rm.detach() if (rm is not None and rm.dtype == torch.float32 and rm.is_cuda) else None
 

@@ -227,6 +227,31 @@ def test_bn_backward_fused_into_the_dgrad_epilogue_gives_the_same_gradients(gpu)
         assert err <= 2e-5 * float(sep[n].abs().max()) + 1e-7 * gn, (n, err)
 
 
+def test_bn_statistics_from_conv_epilogue_partials_match_the_stats_pass(gpu):
+    """training.FUSE_BN_STATS (off by default): one training forward with the statistics merged from the Winograd epilogue's
+    partial sums against the same forward with the separate statistics pass."""
+    c, model, imgs, pts, boxes, labels = _train_case()
+    saved = {n: b.clone() for n, b in model.named_buffers()}
+
+    def run(flag):
+        training.FUSE_BN_STATS = flag
+        for n, b in model.named_buffers():
+            b.copy_(saved[n])
+        try:
+            with torch.enable_grad():
+                out = model(imgs, pts, None)
+        finally:
+            training.FUSE_BN_STATS = False
+        return {k: v.detach().clone() for k, v in out.items()}, {n: b.clone() for n, b in model.named_buffers()}
+
+    (o0, b0), (o1, b1) = run(False), run(True)
+    for k in o0:
+        assert rel_err(o1[k].cpu(), o0[k].cpu()) <= 2e-5, k
+    for n in b0:
+        if b0[n].dtype.is_floating_point:
+            assert rel_err(b1[n].cpu(), b0[n].cpu()) <= 2e-5, n                  # running statistics = batch statistics blended in
+
+
 def test_train_steps_do_not_leak_device_memory(gpu):
     """Activations of a step are released when its backward has run (no autograd reference cycle)."""
     import gc
