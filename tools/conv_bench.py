@@ -22,6 +22,12 @@ SHAPES = {  # name: (N, H, W, Cin, Cout, k, stride, pad)
     "l1_k4": (24, 225, 400, 256, 64, 3, 1, 1),
     "l1_n2": (24, 225, 400, 64, 128, 3, 1, 1),
     "layer1_b1": (6, 225, 400, 64, 64, 3, 1, 1),
+    # B = 8 shapes of the layers that stay on the exact kernel in conv mode "wino" (round 2)
+    "pn5_b8": (8, 1, 35000, 512, 1024, 1, 1, 0),
+    "pn4_b8": (8, 1, 35000, 256, 512, 1, 1, 0),
+    "l2s2_b8": (48, 225, 400, 64, 128, 3, 2, 1),
+    "l3s2_b8": (48, 113, 200, 128, 256, 3, 2, 1),
+    "proj_b8": (48, 57, 100, 256, 512, 1, 1, 0),
     "layer3_b1": (6, 57, 100, 256, 256, 3, 1, 1),
 }
 dev = torch.device("cuda")
