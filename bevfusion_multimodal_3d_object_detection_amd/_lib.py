@@ -88,6 +88,7 @@ SIGNATURES = {
     "bevf_version": (C.c_int, []),
     "bevf_last_error": (C.c_char_p, []),
     "bevf_conv2d_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "bevf_stem_pool_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p]),
     "bevf_stem_conv7x7_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_maxpool3x3s2_nhwc_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_pointwise_smallk_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
@@ -326,6 +327,15 @@ def stem_conv7x7(x: torch.Tensor, w_packed: torch.Tensor, scale, shift, y: torch
         raise BevfError("stem: buffer sizes do not match N,H,W")
     fn = "bevf_stem_conv7x7_f32" if y.dtype == torch.float32 else "bevf_stem_conv7x7_bf16out"
     _check(getattr(lib(), fn)(_pc(x), _pc(w_packed), _pc(scale), _pc(shift), _p(y, y.dtype), N, H, W, int(relu), _stream()), fn)
+
+
+def stem_pool(x: torch.Tensor, w_packed: torch.Tensor, scale, shift, y: torch.Tensor, N: int, H: int, W: int):
+    """stem 7x7/s2 + BN + ReLU + 3x3/s2 max-pool in one kernel: (N,3,H,W) fp32 -> pooled NHWC [N][Hp][Wp][64]."""
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+    if x.numel() != N * 3 * H * W or w_packed.numel() != 148 * 64 or y.numel() < N * Hp * Wp * 64:
+        raise BevfError("stem_pool: buffer sizes do not match N,H,W")
+    _check(lib().bevf_stem_pool_f32(_pc(x), _pc(w_packed), _pc(scale), _pc(shift), _p(y), N, H, W, _stream()), "bevf_stem_pool_f32")
 
 
 def maxpool3x3s2(x: torch.Tensor, y: torch.Tensor, N: int, H: int, W: int, Cc: int):

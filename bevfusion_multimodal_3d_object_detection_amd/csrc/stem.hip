@@ -189,6 +189,148 @@ __global__ __launch_bounds__(256) void stem_conv7x7(const float* __restrict__ x,
   }
 }
 
+// ---- stem + 3x3/s2 max-pool in one kernel (inference, fp32): the 64-channel stem map never reaches HBM -------------------
+// ref src/encoders.py:154-157 (conv1, bn1, relu, maxpool).  The stem output is the largest activation of the whole path
+// (4.4 GB at 48 images of 900x1600); written and read back it costs the separate max-pool 1 ms of pure HBM streaming.
+// Here a workgroup streams DOWN the image: it owns a strip of stem columns and a segment of pooled rows, computes its
+// stem rows four at a time exactly like stem_conv7x7 (same patch staging, same MFMA schedule, same fma / max, so the
+// result is bit-identical to stem -> max-pool), and pools in registers:
+//   * columns: wave w computes stem pixels [30w, 30w+32) of the strip -- two pixels shared with its neighbour -- so the
+//     three columns of every window it owns (centres at its local even pixels 2..30) are its own: no exchange between
+//     waves.  In the 32x32 accumulator layout a lane holds pixels 8g+4h+{0..3}; the window centres are its registers
+//     4g and 4g+2, the only value living in the other lane half (the left neighbour of 4g) comes with four shuffles;
+//   * rows: the horizontal maxima of the last two stem rows stay in registers; every odd stem row 2p+1 completes pooled
+//     row p.  Rows / columns outside the stem map count as 0 (= -inf after a ReLU).
+// A strip is 120 new stem columns (122 computed: +1.7 %), pooled 60; segments of pooled rows are sized on the host so
+// that the grid fills whole rounds of 512 resident workgroups.
+constexpr int WPX = 30, TPS = 4 * WPX;
+
+__global__ __launch_bounds__(256) void stem_pool7x7(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                     float* __restrict__ y, int H, int W, int Ho, int Wo, int Hp, int Wp,
+                                                     int tilesW, int nseg, int rows_per_seg, int vec_ok) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* wl = smem;                      // [KPAD][64]
+  float* patch = smem + KPAD * 64;       // [3][PR][PW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tw = blockIdx.x % tilesW;
+  const int seg = (blockIdx.x / tilesW) % nseg;
+  const int n = blockIdx.x / (tilesW * nseg);
+  const int ow0 = tw * TPS - 2;                                    // even: the patch's 16-byte column loads stay aligned
+  const int p0 = seg * rows_per_seg, p1 = p0 + rows_per_seg < Hp ? p0 + rows_per_seg : Hp;
+  const int r_first = 2 * p0 - 1, r_last = 2 * (p1 - 1) + 1;       // stem rows this segment needs
+  {
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, KPAD * 64 * 4, 0x00020000);
+    const unsigned voff = (unsigned)tid * 16u;
+#pragma unroll
+    for (int it = 0; it < (KPAD * 16 + 255) / 256; ++it) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, voff, it * 4096, 0);
+      if (it * 256 + 255 < KPAD * 16 || tid < KPAD * 16 - it * 256)
+        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(wl) + tid * 16 + it * 4096) = v;
+    }
+  }
+  const int h = lane >> 5, l31 = lane & 31;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int pix = wv * WPX + l31;                                  // stem pixel of the strip this lane feeds to the MFMA
+  const float sc0 = scale[l31], sh0 = shift[l31], sc1 = scale[l31 + 32], sh1 = shift[l31 + 32];
+  const char* const bb = reinterpret_cast<const char*>(wl) + l31 * 4;
+  const char* const pb[3] = {bb + h * 7 * 256, bb + h * 256, bb + h * 49 * 256};
+  const int col0 = ow0 + wv * WPX + 4 * h;                         // stem column of register 0 of this lane
+  const bool edge_cols = ow0 < 0 || ow0 + TPS + 2 > Wo;            // workgroup-uniform
+  // pooled column of centre register rc = 2c: (col0 + (rc&3) + 8*(rc>>2)) / 2
+  float prev1[16], prev2[16];                                      // horizontal maxima of the last two stem rows: [acc][centre]
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { prev1[i] = 0.f; prev2[i] = 0.f; }
+
+  for (int oh0 = r_first; oh0 <= r_last; oh0 += TH) {
+    __syncthreads();                                               // the previous chunk's patch is fully consumed
+    stage_patch(x, patch, n, H, W, oh0, ow0, vec_ok, tid, lane, wave);
+    __syncthreads();
+    for (int ro = 0; ro < TH; ++ro) {
+      const int oh = oh0 + ro;
+      if (oh > r_last) break;
+      const char* const ab = reinterpret_cast<const char*>(patch) + (2 * ro * PW + 2 * pix) * 4;
+      const char* const pa[4] = {ab + h * PW * 4, ab + h * 4, ab + h * PR * PW * 4, ab};
+      f32x16 acc0, acc1;
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      constexpr int CH = 4, NCH = (NSTEP + CH - 1) / CH;
+      float av[2][CH], b0v[2][CH], b1v[2][CH];
+      auto load_chunk = [&](int cidx, int set) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const int p = cidx * CH + u;
+          if (p < NSTEP) {
+            const StemStep st = stem_step(p);
+            const char* const bp = pb[st.grp == 3 ? 1 : st.grp];
+            av[set][u] = *reinterpret_cast<const float*>(pa[st.grp] + st.a_imm);
+            b0v[set][u] = *reinterpret_cast<const float*>(bp + st.b_imm);
+            b1v[set][u] = *reinterpret_cast<const float*>(bp + st.b_imm + 128);
+          }
+        }
+      };
+      load_chunk(0, 0);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH) load_chunk(c + 1, (c + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          if (c * CH + u < NSTEP) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c & 1][u], b0v[c & 1][u], c == 0 && u == 0 ? zero : acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c & 1][u], b1v[c & 1][u], c == 0 && u == 0 ? zero : acc1, 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // BatchNorm + ReLU exactly as stem_conv7x7 stores them; stem rows / columns that do not exist count as 0
+      const bool row_ok = (unsigned)oh < (unsigned)Ho;             // uniform
+      float v0[16], v1[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool ok = row_ok && (!edge_cols || (unsigned)(col0 + (r & 3) + 8 * (r >> 2)) < (unsigned)Wo);
+        v0[r] = ok ? fmaxf(fmaf(acc0[r], sc0, sh0), 0.f) : 0.f;
+        v1[r] = ok ? fmaxf(fmaf(acc1[r], sc1, sh1), 0.f) : 0.f;
+      }
+      // horizontal 3-max at the centres rc = 0, 2, .., 14 (pixel 8g + 4h + {0, 2}); the left neighbour of rc = 4g lives in
+      // the other lane half: register 4g+3 of half 0 for h = 1, register 4g-1 of half 1 for h = 0 (g = 0, h = 0: no centre)
+      float hm[16];
+      float x0[4], x1[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        x0[g] = __shfl_xor(v0[4 * g + 3], 32);
+        x1[g] = __shfl_xor(v1[4 * g + 3], 32);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float l0 = h ? x0[g] : (g > 0 ? x0[g - 1] : 0.f), l1 = h ? x1[g] : (g > 0 ? x1[g - 1] : 0.f);
+        hm[2 * g] = fmaxf(fmaxf(l0, v0[4 * g]), v0[4 * g + 1]);
+        hm[2 * g + 1] = fmaxf(fmaxf(v0[4 * g + 1], v0[4 * g + 2]), v0[4 * g + 3]);
+        hm[8 + 2 * g] = fmaxf(fmaxf(l1, v1[4 * g]), v1[4 * g + 1]);
+        hm[8 + 2 * g + 1] = fmaxf(fmaxf(v1[4 * g + 1], v1[4 * g + 2]), v1[4 * g + 3]);
+      }
+      if (oh & 1) {                                                // stem row 2p+1 completes pooled row p (uniform branch)
+        const int pr = (oh - 1) >> 1;
+        if (pr >= p0 && pr < p1) {
+          float* const yrow = y + ((size_t)(n * Hp + pr) * Wp) * 64 + l31;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            const int rc = 2 * c;
+            const int col = col0 + (rc & 3) + 8 * (rc >> 2);       // stem column of the window centre (even)
+            const bool own = (h != 0 || c != 0) && col >= 0 && (col >> 1) < Wp;   // (h = 0, rc = 0 is the neighbour's window)
+            if (own) {
+              float* const dst = yrow + (size_t)(col >> 1) * 64;
+              dst[0] = fmaxf(fmaxf(prev2[c], prev1[c]), hm[c]);
+              dst[32] = fmaxf(fmaxf(prev2[8 + c], prev1[8 + c]), hm[8 + c]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { prev2[i] = prev1[i]; prev1[i] = hm[i]; }
+    }
+  }
+}
+
 // ---- weight gradient of the stem: dW[co][k] = sum over pixels dY[pixel][co] * patch(pixel, tap k) --------------------
 // Same tile (TH rows x TP pixels of one image, patch in LDS) as the forward.  Per output row the dY row tile
 // [128 pixels][64 channels] is staged next to the patch; MFMA tiles C[i = channel][j = tap] (2 x 5 tiles of 32x32, 160
@@ -343,6 +485,38 @@ extern "C" int bevf_stem_conv7x7_f32(const float* x, const float* w, const float
 extern "C" int bevf_stem_conv7x7_bf16out(const float* x, const float* w, const float* scale, const float* shift,
                                          void* y, int N, int H, int W, int relu, void* stream) {
   return stem_entry<__bf16>(x, w, scale, shift, y, N, H, W, relu, stream);
+}
+
+// stem + max-pool fused (fp32 in, fp32 pooled NHWC out [N][Hp][Wp][64]); bit-identical to bevf_stem_conv7x7_f32 (relu) followed
+// by bevf_maxpool3x3s2_nhwc_f32
+extern "C" int bevf_stem_pool_f32(const float* x, const float* w, const float* scale, const float* shift, float* y, int N,
+                                  int H, int W, void* stream) {
+  BEVF_REQUIRE(x && w && scale && shift && y, "stem_pool: null pointer");
+  BEVF_REQUIRE(bevf_aligned16(w), "stem_pool: packed filter bank must be 16-byte aligned");
+  BEVF_REQUIRE(N > 0 && H >= 1 && W >= 1, "stem_pool: empty shape");
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+  const int Hp = (Ho + 2 - 3) / 2 + 1, Wp = (Wo + 2 - 3) / 2 + 1;
+  const int tilesW = (Wp + TPS / 2 - 1) / (TPS / 2);
+  // segments of pooled rows: fewest (rounds of 512 resident workgroups) x (chunks of 4 stem rows per workgroup)
+  int best_seg = 1;
+  long long best_cost = -1;
+  for (int ns = 1; ns <= 32 && ns <= Hp; ++ns) {
+    const int rps = (Hp + ns - 1) / ns, real = (Hp + rps - 1) / rps;
+    const long long wgs = (long long)N * tilesW * real;
+    const long long cost = ((wgs + 511) / 512) * ((2 * rps + 1 + TH - 1) / TH);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_seg = real; }
+  }
+  const int rps = (Hp + best_seg - 1) / best_seg, nseg = (Hp + rps - 1) / rps;
+  const long long grid = (long long)N * tilesW * nseg;
+  BEVF_REQUIRE(grid < (1ll << 31), "stem_pool: grid too large");
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool7x7), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStemLds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(stem_pool7x7, dim3((unsigned)grid), dim3(256), kStemLds, static_cast<hipStream_t>(stream), x, w, scale, shift, y,
+                     H, W, Ho, Wo, Hp, Wp, tilesW, nseg, rps, (W % 4 == 0 && bevf_aligned16(x)) ? 1 : 0);
+  return bevf_check_launch("bevf_stem_pool_f32");
 }
 
 template <typename T>

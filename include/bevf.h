@@ -105,6 +105,11 @@ int bevf_wino_stat_rows(int N, int H, int W);   /* rows of the `stats` partial b
  * y: [N][Ho][Wo][64] NHWC.                                                                  */
 int bevf_stem_conv7x7_f32(const float* x, const float* w, const float* scale, const float* shift,
                           float* y, int N, int H, int W, int relu, void* stream);
+/* conv1 + bn1 + relu + maxpool(3, stride 2, pad 1) of ref src/encoders.py:154-157 in ONE kernel (inference): y is the pooled
+ * NHWC map [N][Hp][Wp][64]; the stem map itself (the largest activation of the path) never reaches HBM.  Bit-identical to
+ * bevf_stem_conv7x7_f32(relu = 1) followed by bevf_maxpool3x3s2_nhwc_f32. */
+int bevf_stem_pool_f32(const float* x, const float* w_packed, const float* scale, const float* shift, float* y, int N,
+                       int H, int W, void* stream);
 
 /* 3x3 stride-2 pad-1 max-pool, NHWC, ref src/encoders.py:157.                               */
 int bevf_maxpool3x3s2_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
