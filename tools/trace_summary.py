@@ -7,7 +7,7 @@ path, steps = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 7
 rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
 ours = [r for r in rows]
 # one step = from one stem launch to the next
-idx = [i for i, r in enumerate(ours) if "stem_conv7x7" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(ours) if "stem_conv7x7" in r["Kernel_Name"] or "stem_pool7x7" in r["Kernel_Name"]]
 if len(idx) >= 2:
     lo, hi = idx[-2], idx[-1]
 else:
