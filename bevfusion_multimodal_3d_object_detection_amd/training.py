@@ -136,21 +136,39 @@ def conv_raw(x, w_ohwi, bias, N, H, W, cin, cout, k, stride, pad, relu=False, bn
     return y, Ho, Wo
 
 
+# 3x3 / stride 1 / pad 1 weight gradients with channels in multiples of 64 run in the Winograd domain (csrc/conv_wino_wgrad.hip:
+# 2.25x fewer MFMA FLOPs, deterministic); False = the pixel-GEMM with atomics everywhere (the round-1 path)
+WINO_WGRAD = True
+
+
 def conv_wgrad(x, dy, N, H, W, cin, cout, k, stride, pad, dw=None) -> torch.Tensor:
     """Returns dW in OHWI layout [cout][k][k][cin] (accumulates into `dw` when given)."""
-    if dw is None:
-        dw = _zeros(cout * k * k * cin, x.device)
+    fresh = dw is None
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     per = _image_chunk(N, H * W * cin, Ho * Wo * cout, Ho * Wo * k * k)          # (the tap table has the same limit)
     if per < N:
+        if fresh:
+            dw = _zeros(cout * k * k * cin, x.device)
         for i0 in range(0, N, per):
             n = min(per, N - i0)
             conv_wgrad(x[i0 * H * W * cin:], dy[i0 * Ho * Wo * cout:], n, H, W, cin, cout, k, stride, pad, dw=dw)
         return dw[:cout * k * k * cin].view(cout, k, k, cin)
+    flops = 2.0 * N * Ho * Wo * cout * k * k * cin
+    ws = _lib().bevf_wino_wgrad_workspace_floats(N, H, W, cin, cout) if WINO_WGRAD and (k, stride, pad) == (3, 1, 1) else 0
+    if ws:
+        if fresh:
+            dw = _new(cout * 9 * cin, x.device)
+        d = L.WgradDesc(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, N, H, W, cin, cin, cout, cout, 3, 3, 1, 1)
+        work = _new(ws, x.device)
+        with E._span("conv_wgrad_wino_f32", flops=flops):
+            _ck(_lib().bevf_conv3x3_wgrad_wino_f32(C.byref(d), work.data_ptr(), 0 if fresh else 1, _st()),
+                "bevf_conv3x3_wgrad_wino_f32")
+        return dw[:cout * 9 * cin].view(cout, 3, 3, cin)
+    if fresh:
+        dw = _zeros(cout * k * k * cin, x.device)
     d = L.WgradDesc(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _pixtab(N, H, W, k, stride, pad, cin, x.device).data_ptr(),
                     N, H, W, cin, cin, cout, cout, k, k, stride, pad)
-    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    with E._span("conv_wgrad_f32", flops=2.0 * N * Ho * Wo * cout * k * k * cin):
+    with E._span("conv_wgrad_f32", flops=flops):
         _ck(_lib().bevf_conv2d_wgrad_f32(C.byref(d), _st()), "bevf_conv2d_wgrad_f32")
     return dw[:cout * k * k * cin].view(cout, k, k, cin)
 

@@ -349,6 +349,12 @@ typedef struct {
   int32_t N, H, W, Cin, x_cs, Cout, dy_cs, KH, KW, stride, pad;
 } bevf_wgrad_desc;
 int bevf_conv2d_wgrad_f32(const bevf_wgrad_desc* d, void* stream);
+/* The same gradient for 3x3 / stride 1 / pad 1 layers with Cin, Cout multiples of 64, in the Winograd F(2x2,3x3) domain
+ * (csrc/conv_wino_wgrad.hip): 2.25x fewer MFMA FLOPs, deterministic (fixed-order sum of per-workgroup partial blocks, no
+ * atomics).  `workspace`: bevf_wino_wgrad_workspace_floats() floats (0 = shape not supported: use bevf_conv2d_wgrad_f32);
+ * `pixtab` of the descriptor is not used; accumulate != 0 adds to dw instead of overwriting it.  dw: [Cout][3][3][Cin]. */
+size_t bevf_wino_wgrad_workspace_floats(int N, int H, int W, int Cin, int Cout);
+int bevf_conv3x3_wgrad_wino_f32(const bevf_wgrad_desc* d, float* workspace, int accumulate, void* stream);
 
 /* Data gradient: the forward kernel (bevf_conv2d_nhwc_f32) run on dy with the spatially flipped, channel-
  * transposed filter; strided convs first spread dy onto the input grid with zeros in between:            */

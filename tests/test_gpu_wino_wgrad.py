@@ -1,0 +1,95 @@
+"""Weight gradient of the 3x3 / stride 1 / pad 1 convolution in the Winograd domain (csrc/conv_wino_wgrad.hip) against torch
+autograd of F.conv2d (ref: every nn.Conv2d(k=3, padding=1) of src/encoders.py / src/fusion.py under loss.backward(),
+train_detect.py:424), and against the pixel-GEMM kernel it replaces.  Tolerance: 2e-5 of max |dW| (fp32 products and
+sums in a different order: measured 2-3e-7)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from bevfusion_multimodal_3d_object_detection_amd import _lib as L
+from bevfusion_multimodal_3d_object_detection_amd import synth, training
+from tests.conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous().view(-1).cuda()
+
+
+def autograd_dw(x, dy, cout, cin):
+    w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x.double(), w, None, 1, 1)
+    (g,) = torch.autograd.grad(y, w, dy.double())
+    return g.permute(0, 2, 3, 1)                                        # OHWI, like training.conv_wgrad
+
+
+# odd / even sizes, one-tile rows, 64-channel blocks on either side, a tile range shorter than the chip (few splits) and
+# one long enough that every split holds many steps and the two-level sum runs (splits > 16)
+@pytest.mark.parametrize("N,H,W,cin,cout", [(2, 13, 21, 64, 64), (1, 33, 18, 128, 64), (3, 8, 7, 64, 192), (1, 3, 3, 64, 64),
+                                             (2, 4, 5, 128, 128), (6, 56, 100, 64, 64), (1, 14, 25, 256, 128)])
+def test_wino_wgrad_matches_autograd(gpu, monkeypatch, N, H, W, cin, cout):
+    x = synth.normal((N, cin, H, W), 11)
+    dy = synth.normal((N, cout, H, W), 12)
+    ref = autograd_dw(x, dy, cout, cin)
+    assert L.lib().bevf_wino_wgrad_workspace_floats(N, H, W, cin, cout) > 0
+    monkeypatch.setattr(training, "WINO_WGRAD", True)
+    dw = training.conv_wgrad(nhwc(x), nhwc(dy), N, H, W, cin, cout, 3, 1, 1)
+    assert float((dw.cpu().double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    # deterministic: no atomics, fixed summation order
+    again = training.conv_wgrad(nhwc(x), nhwc(dy), N, H, W, cin, cout, 3, 1, 1)
+    assert torch.equal(dw, again)
+    # and the kernel it replaces agrees
+    monkeypatch.setattr(training, "WINO_WGRAD", False)
+    gemm = training.conv_wgrad(nhwc(x), nhwc(dy), N, H, W, cin, cout, 3, 1, 1)
+    assert rel_err(dw.cpu(), gemm.cpu()) <= 2e-5
+
+
+def test_wino_wgrad_zero_rows_and_columns_of_padding(gpu):
+    """A gradient that lives only on the image border exercises every out-of-image read (pad ring, odd last row/column)."""
+    N, H, W, cin, cout = 1, 9, 11, 64, 64
+    x = synth.normal((N, cin, H, W), 21)
+    dy = torch.zeros(N, cout, H, W)
+    dy[:, :, 0, :] = synth.normal((N, cout, W), 22)
+    dy[:, :, -1, :] = synth.normal((N, cout, W), 23)
+    dy[:, :, :, 0] = synth.normal((N, cout, H), 24)
+    dy[:, :, :, -1] = synth.normal((N, cout, H), 25)
+    ref = autograd_dw(x, dy, cout, cin)
+    dw = training.conv_wgrad(nhwc(x), nhwc(dy), N, H, W, cin, cout, 3, 1, 1)
+    assert float((dw.cpu().double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+def test_wino_wgrad_accumulates_over_image_chunks(gpu, monkeypatch):
+    """Past the 2 GiB operand limit the batch runs as image chunks that accumulate into one dW (limit shrunk here)."""
+    N, H, W, cin, cout = 5, 12, 10, 64, 128
+    x, dy = synth.normal((N, cin, H, W), 31), synth.normal((N, cout, H, W), 32)
+    whole = training.conv_wgrad(nhwc(x), nhwc(dy), N, H, W, cin, cout, 3, 1, 1).clone()
+    monkeypatch.setattr(training, "BUF_LIMIT", 2 * H * W * max(cin, cout) * 4 + 64)        # two images per launch
+    parts = training.conv_wgrad(nhwc(x), nhwc(dy), N, H, W, cin, cout, 3, 1, 1)
+    assert rel_err(parts.cpu(), whole.cpu()) <= 1e-6
+    assert rel_err(parts.cpu(), autograd_dw(x, dy, cout, cin).float()) <= 2e-5
+
+
+def test_wino_wgrad_refuses_what_it_cannot_do(gpu):
+    """Channel counts off the 64 grid report no workspace (the host then takes the pixel-GEMM kernel); calling the entry
+    point anyway fails loudly, as does a non-3x3 descriptor."""
+    lib = L.lib()
+    assert lib.bevf_wino_wgrad_workspace_floats(2, 9, 13, 32, 64) == 0
+    assert lib.bevf_wino_wgrad_workspace_floats(2, 9, 13, 64, 96) == 0
+    assert lib.bevf_wino_wgrad_workspace_floats(2, 2, 13, 64, 64) == 0
+    x = torch.zeros(2 * 9 * 13 * 64, device="cuda")
+    dw = torch.zeros(64 * 9 * 64, device="cuda")
+    work = torch.zeros(1 << 20, device="cuda")
+    d = L.WgradDesc(x.data_ptr(), x.data_ptr(), dw.data_ptr(), None, 2, 9, 13, 32, 32, 64, 64, 3, 3, 1, 1)
+    assert lib.bevf_conv3x3_wgrad_wino_f32(C.byref(d), work.data_ptr(), 0, None) != 0
+    assert b"unsupported shape" in lib.bevf_last_error()
+    d = L.WgradDesc(x.data_ptr(), x.data_ptr(), dw.data_ptr(), None, 2, 9, 13, 64, 64, 64, 64, 3, 3, 2, 1)
+    assert lib.bevf_conv3x3_wgrad_wino_f32(C.byref(d), work.data_ptr(), 0, None) != 0
+    # the host wrapper routes such layers to the pixel-GEMM kernel
+    xs, dys = synth.normal((2, 32, 9, 13), 41), synth.normal((2, 64, 9, 13), 42)
+    w = torch.zeros(64, 32, 3, 3, requires_grad=True)
+    (g,) = torch.autograd.grad(F.conv2d(xs, w, None, 1, 1), w, dys)
+    dw = training.conv_wgrad(nhwc(xs), nhwc(dys), 2, 9, 13, 32, 64, 3, 1, 1)
+    assert rel_err(dw.permute(0, 3, 1, 2).cpu(), g) <= 2e-5
