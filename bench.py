@@ -281,14 +281,17 @@ def run_leg(config, dtype, mode, batch, steps, warmup, ctx, graph=False, kernel_
         conv = tot.get("conv_igemm_f32")
         wino = tot.get("conv_wino_f32")
         executed = conv["flops"] if conv else 0.0                 # FLOPs the matrix pipe really executes
+        wino_flops = wino["flops"] if wino else 0.0
         if wino:                                                  # Winograd F(2x2,3x3): 16 multiplies per 36 algorithmic ones
             executed += wino["flops"] * 16.0 / 36.0
             conv = {k: conv[k] + wino[k] for k in conv} if conv else wino
         if conv and mode == "train":                          # forward + data-gradient + weight-gradient GEMMs
-            for extra in ("conv_dgrad_f32", "conv_wgrad_f32"):
+            for extra in ("conv_dgrad_f32", "conv_wgrad_f32", "conv_wgrad_wino_f32"):
                 e = tot.get(extra)
                 if e:
                     conv = {k: conv[k] + e[k] for k in conv}
+                    executed += e["flops"] * (16.0 / 36.0 if extra == "conv_wgrad_wino_f32" else 1.0)
+                    wino_flops += e["flops"] if extra == "conv_wgrad_wino_f32" else 0.0
         if conv:
             ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
             # f32x3 spends six bf16 MFMA products per algorithmic multiply-add: its ceiling is a sixth of the bf16 peak
@@ -296,7 +299,8 @@ def run_leg(config, dtype, mode, batch, steps, warmup, ctx, graph=False, kernel_
             kname = {"fp32": "conv_igemm_f32", "bf16": "conv_igemm_bf16", "f32x3": "conv_split_f32x3"}[dtype]
             if wino:
                 kname = "conv_wino_f32+conv_igemm_f32"
-            rec["roofline"] = {"kernel": kname if mode == "infer" else "conv_igemm_f32+conv_wgrad_f32",
+            rec["roofline"] = {"kernel": kname if mode == "infer" else "conv fwd + dgrad + wgrad (wino_f32, conv_igemm_f32, "
+                                                                       "wino_wgrad_f32, conv_wgrad_f32)",
                                "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                "traffic": None, "traffic_source": None,
                                "launches_per_step": conv["launches"] / timer_steps,
@@ -304,11 +308,11 @@ def run_leg(config, dtype, mode, batch, steps, warmup, ctx, graph=False, kernel_
                                "gflop_per_step": conv["flops"] / timer_steps / 1e9,
                                "share_of_step": conv["ms"] / (1e3 * timer_elapsed),
                                "measured_over": "the timed region" if timer_in_region else "2 untimed steps after the timed region"}
-            if wino and mode == "infer":
+            if wino:
                 # `achieved` counts ALGORITHMIC (direct-convolution) FLOPs, as SURVEY.md 8d tabulates them; the Winograd layers
                 # execute 16/36 of theirs, so the matrix pipe's own utilisation is reported beside it
                 ex = executed / (conv["ms"] * 1e-3) / 1e12
-                rec["roofline"]["executed"] = {"tflops": ex, "frac": ex / peak, "wino_share_of_flops": wino["flops"] / conv["flops"]}
+                rec["roofline"]["executed"] = {"tflops": ex, "frac": ex / peak, "wino_share_of_flops": wino_flops / conv["flops"]}
             tr = pmc_traffic(config, batch) if dtype == "fp32" and mode == "infer" else None
             if tr is not None:
                 rec["roofline"]["traffic"], rec["roofline"]["traffic_source"] = tr

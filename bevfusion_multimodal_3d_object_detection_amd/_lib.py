@@ -142,6 +142,8 @@ SIGNATURES = {
     "bevf_conv_pixtab": (C.c_int, [C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
     "bevf_conv2d_wgrad_f32": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
     "bevf_wino_wgrad_workspace_floats": (C.c_size_t, [C.c_int] * 5),
+    "bevf_wino_wgrad_table_bytes": (C.c_size_t, [C.c_int] * 3),
+    "bevf_wino_wgrad_table": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
     "bevf_conv3x3_wgrad_wino_f32": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p, C.c_int, C.c_void_p]),
     "bevf_zero_stuff_nhwc_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 7 + [C.c_void_p]),
     "bevf_stem_wgrad_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),

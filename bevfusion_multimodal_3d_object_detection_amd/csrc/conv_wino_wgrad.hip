@@ -16,15 +16,22 @@
 // HBM/L2 into registers, the 16 bytes (channels 4q..4q+3 of the block) of each pixel it needs of tile k:
 //   X : rows rA, rB of the 4x4 patch (frequency row fr of B^T X combines exactly two rows) x 4 columns   8 x b128
 //   dY: both rows x 2 columns (a row the frequency row does not use is answered with zeros by the buffer unit)  4 x b128
-// Out-of-image pixels (the pad ring, the odd last row / column, tiles past the end) are out-of-range offsets of the
-// buffer descriptor and read as 0.  Component e of a lane's 16 bytes is channel 4q + e: MFMA block e of the operand
-// therefore holds channels {4q + e}, a permutation that the store of the partial sums undoes for free.
-// Per k-step a wave issues 64 MFMAs (2048 cycles of the matrix pipe) against 12 loads and ~100 VALU instructions, all
-// pinned one small piece between two MFMAs (sched_barrier) as in conv_wino.hip; operands are computed one step ahead,
-// loads run two steps ahead.
+// Component e of a lane's 16 bytes is channel 4q + e: MFMA block e of the operand therefore holds channels {4q + e}, a
+// permutation that the store of the partial sums undoes for free.
+// The fp32 MFMA shares the vector ALU (a pure-MFMA loop runs at 96 % of peak; every VALU instruction added to it costs its
+// own issue time on top), so the loop is built to need almost none:
+//   * pixel addresses come from a per-shape TABLE (bevf_wino_wgrad_table: per tile the 16 X and 3 x 4 dY byte offsets,
+//     0x80000000 = "does not exist" for the pad ring, the odd last row / column and tiles past the end -- the buffer unit
+//     answers those with 0); a lane fetches its tile's entries two steps ahead (3 x b128) and adds its channel offset: 12
+//     v_add per step, no division, no compare, no select;
+//   * the transforms are packed-fp32 inline asm (v_pk_fma_f32 / v_pk_add_f32 with neg modifiers): 24 per step;
+//   * everything else (table / data loads, loop control) is VMEM / SALU.
+// Per k-step a wave issues 64 MFMAs (2048 cycles of the matrix pipe) against 36 VALU instructions, each pinned in its
+// own MFMA gap (asm volatile keeps program order; sched_barrier binds the loads).  Operands are computed one step
+// ahead, pixels are loaded two steps ahead, table entries three.
 // The tile range is split over 256 / (block pairs) workgroups; each writes its partial [16 f][64][64] block to a
-// workspace and wino_wgrad_reduce sums the splits in a fixed order (deterministic, unlike the atomics of
-// conv_wgrad.hip), applies G^T . G and writes (or accumulates into) dW [Cout][3][3][Cin].
+// workspace, summed in a fixed order (deterministic, unlike the atomics of conv_wgrad.hip) by the two kernels below,
+// which also apply G^T . G and write (or accumulate into) dW [Cout][3][3][Cin].
 #include "conv_common.h"
 
 #include <type_traits>
@@ -33,16 +40,83 @@ namespace {
 
 #define MFMA(acc_, a_, b_) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc_) : "v"(a_), "v"(b_))
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// packed fp32 VALU as volatile asm: stays where it is written between the (volatile asm) MFMAs
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+  f32x2 d;
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ unsigned v_add(int a, int b) {
+  unsigned d;
+  asm volatile("v_add_u32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ f32x2 lo2(f32x4 v) { return __builtin_shufflevector(v, v, 0, 1); }
+__device__ __forceinline__ f32x2 hi2(f32x4 v) { return __builtin_shufflevector(v, v, 2, 3); }
+
+// table entry of one tile: 28 dwords
+//   [4 r + c]      X byte offset of patch pixel (r, c), r, c = 0..3 (patch origin (2 ty - 1, 2 tx - 1))
+//   [16 + 2 r + c] dY byte offset of pixel (r, c) of the tile's 2x2 block
+//   [20 + ..]      the same with row 1 removed (frequency row 0 of A dY = dY row 0)
+//   [24 + ..]      the same with row 0 removed (frequency row 3 = - dY row 1)
+constexpr int TE = 28, TE_BYTES = TE * 4;
+
 struct WwArgs {
   const float* x;      // NHWC, channel stride x_cs
   const float* dy;     // NHWC, channel stride dy_cs
+  const int* tab;      // [4 (steps + 4)][TE]
   float* part;         // [splits][16 f][Cout][Cin]
-  int H, W, x_cs, dy_cs, Cin, Cout;
-  int tilesX, tilesY, T;            // tiles per row, rows of tiles per image, tiles in the batch
-  unsigned mX, mY;                  // floor(2^32 / tilesX) + 1, floor(2^32 / tilesY) + 1: exact umulhi division below 2^32 / d
+  int Cin, Cout;
   int steps, steps_per_split;       // k-steps of 4 tiles
   int nci, nco;                     // 64-channel blocks
 };
+
+__global__ __launch_bounds__(256) void wino_wgrad_table(int* __restrict__ tab, int H, int W, int tilesX, int tilesY, int T,
+                                                         int Tpad, int xs4, int ys4) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= Tpad) return;
+  int e[TE];
+#pragma unroll
+  for (int i = 0; i < TE; ++i) e[i] = (int)kOob;
+  if (t < T) {
+    const int n = t / (tilesX * tilesY), rem = t - n * tilesX * tilesY, ty = rem / tilesX, tx = rem - ty * tilesX;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int y = 2 * ty - 1 + r, x = 2 * tx - 1 + c;
+        if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) e[4 * r + c] = ((n * H + y) * W + x) * xs4;
+      }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int y = 2 * ty + r, x = 2 * tx + c;
+        if (y < H && x < W) {
+          const int o = ((n * H + y) * W + x) * ys4;
+          e[16 + 2 * r + c] = o;
+          if (r == 0) e[20 + c] = o;
+          else e[26 + c] = o;
+        }
+      }
+  }
+  i32x4* dst = reinterpret_cast<i32x4*>(tab + (size_t)t * TE);
+#pragma unroll
+  for (int i = 0; i < TE / 4; ++i) dst[i] = i32x4{e[4 * i], e[4 * i + 1], e[4 * i + 2], e[4 * i + 3]};
+}
 
 template <int C> using ic = std::integral_constant<int, C>;
 
@@ -54,18 +128,24 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_f32(const WwArgs p) {
   const int co0 = (pair / p.nci) * 64, ci0 = (pair % p.nci) * 64;
   const int s_begin = split * p.steps_per_split;
   const int s_end = s_begin + p.steps_per_split < p.steps ? s_begin + p.steps_per_split : p.steps;
-  // frequency row fr of B^T X = x[rA] + sB * x[rB];  of A dY = cA * dy[0] + cB * dy[1]
+  // frequency row fr of B^T X = x[rA] + sB * x[rB];  of A dY = dy[0] + cB * dy[1] (the table removes the row a frequency
+  // row does not contain: fr 0 reads dy[1] = 0, fr 3 reads dy[0] = 0)
   const int rA = fr == 0 ? 0 : (fr == 2 ? 2 : 1);
   const int rB = fr == 2 ? 1 : (fr == 3 ? 3 : 2);
-  const float sB = fr == 1 ? 1.f : -1.f;
-  const float cA = fr == 3 ? 0.f : 1.f, cB = fr == 0 ? 0.f : (fr == 1 ? 1.f : -1.f);
+  const float sBs = fr == 1 ? 1.f : -1.f, cBs = fr == 1 ? 1.f : -1.f;
+  const f32x2 sB = {sBs, sBs}, cB = {cBs, cBs};
+  const int selA = rA * 16, selB = rB * 16, selY = fr == 0 ? 80 : (fr == 3 ? 96 : 64);      // byte offsets inside a table entry
   const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + ci0), 0, (int)kOob, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy + co0), 0, (int)kOob, 0x00020000);
-  const int xs4 = p.x_cs * 4, ys4 = p.dy_cs * 4, q16 = q * 16;
+  const __amdgpu_buffer_rsrc_t rst =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(p.tab), 0, 4 * (p.steps + 4) * TE_BYTES, 0x00020000);
+  const int q16 = q * 16, ktab = k * TE_BYTES;
 
   f32x4 acc[4][4][4];                                 // [fc][co block][ci block]
-  f32x4 rx[2][2][4], ry[2][2][2];                     // raw loads [set][row][col]
-  f32x4 ao[2][4], bo[2][4];                           // MFMA operands [set][fc], component = channel block
+  f32x4 rx[2][2][4], ry[2][2][2];                     // raw pixels [set][row][col]
+  i32x4 tab[2][3];                                    // table entries [set][row A, row B, dY] of the steps whose pixels are loaded next
+  // MFMA operands [set]: B side bo[fc][half]; A side fc 0 = r[0], fc 1 = a1, fc 2 = a2, fc 3 = r[1] (sign folded into the final sum)
+  f32x2 bo[2][4][2], rr[2][2][2], a1[2][2], a2[2][2], v_[4][2];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -73,105 +153,53 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_f32(const WwArgs p) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[a][b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- address generation of one k-step: byte offsets of the lane's tile, kOob where the pixel does not exist -----
-  unsigned t_, row_;
-  int tx_, ty_, n_, xb_, yb_;
-  bool okA_, okB_, ok0_, ok1_;
-  // (PIN: an empty asm that "rewrites" a value -- hipcc cannot move the arithmetic consuming it above this point, so
-  //  each piece stays in the MFMA gap it was written in; sched_barrier alone only binds the machine scheduler)
-#define PIN(v_) asm volatile("" : "+v"(v_))
-  auto addr_a = [&](int s) {
-    t_ = 4u * (unsigned)s + (unsigned)k;
-    PIN(t_);
-    row_ = __umulhi(t_, p.mX);                        // n * tilesY + ty
-    tx_ = (int)(t_ - row_ * (unsigned)p.tilesX);
-    PIN(tx_);
+  auto load_tab = [&](auto setc, int s, auto wc) {    // entries of tile-step s
+    constexpr int set = decltype(setc)::value, which = decltype(wc)::value;
+    const int so = s * 4 * TE_BYTES + (which == 0 ? selA : which == 1 ? selB : selY);
+    tab[set][which] = __builtin_bit_cast(i32x4, buf_load16(rst, ktab, so));
   };
-  auto addr_b = [&]() {
-    PIN(row_);
-    n_ = (int)__umulhi(row_, p.mY);
-    ty_ = (int)row_ - n_ * p.tilesY;
-    PIN(ty_);
-    PIN(n_);
+  auto load_px = [&](auto setc, auto tsetc, auto ic_) {   // pixel i of table set tset: 0..3 row A, 4..7 row B, 8..11 dY
+    constexpr int set = decltype(setc)::value, ts = decltype(tsetc)::value, i = decltype(ic_)::value;
+    if constexpr (i < 4) rx[set][0][i] = buf_load16(rsx, v_add(tab[ts][0][i], q16), 0);
+    else if constexpr (i < 8) rx[set][1][i - 4] = buf_load16(rsx, v_add(tab[ts][1][i - 4], q16), 0);
+    else ry[set][(i - 8) >> 1][(i - 8) & 1] = buf_load16(rsy, v_add(tab[ts][2][i - 8], q16), 0);
   };
-  auto addr_c = [&](int s) {
-    PIN(ty_);
-    const bool live = s < s_end && t_ < (unsigned)p.T;
-    const int y0 = 2 * ty_ - 1;
-    okA_ = live && (unsigned)(y0 + rA) < (unsigned)p.H;
-    okB_ = live && (unsigned)(y0 + rB) < (unsigned)p.H;
-    ok0_ = live && fr != 3;
-    ok1_ = live && fr != 0 && 2 * ty_ + 1 < p.H;
+  auto xform = [&](auto setc, auto jc) {              // transform step j of raw set -> operand set, one packed instruction each
+    constexpr int set = decltype(setc)::value, j = decltype(jc)::value;
+    if constexpr (j < 8) {                            // rows of B^T X: v[c] = x[rA][c] + sB x[rB][c]
+      constexpr int c = j >> 1, h = j & 1;
+      v_[c][h] = pk_fma(sB, h ? hi2(rx[set][1][c]) : lo2(rx[set][1][c]), h ? hi2(rx[set][0][c]) : lo2(rx[set][0][c]));
+    } else if constexpr (j < 16) {                    // columns: v0 - v2, v1 + v2, v2 - v1, v1 - v3
+      constexpr int fc = (j - 8) >> 1, h = j & 1;
+      if constexpr (fc == 0) bo[set][0][h] = pk_sub(v_[0][h], v_[2][h]);
+      if constexpr (fc == 1) bo[set][1][h] = pk_add(v_[1][h], v_[2][h]);
+      if constexpr (fc == 2) bo[set][2][h] = pk_sub(v_[2][h], v_[1][h]);
+      if constexpr (fc == 3) bo[set][3][h] = pk_sub(v_[1][h], v_[3][h]);
+    } else if constexpr (j < 20) {                    // rows of A dY: r[c] = dy[0][c] + cB dy[1][c]
+      constexpr int c = (j - 16) >> 1, h = j & 1;
+      rr[set][c][h] = pk_fma(cB, h ? hi2(ry[set][1][c]) : lo2(ry[set][1][c]), h ? hi2(ry[set][0][c]) : lo2(ry[set][0][c]));
+    } else {                                          // columns: r0, r0 + r1, r0 - r1, (-) r1
+      constexpr int h = j & 1;
+      if constexpr (j < 22) a1[set][h] = pk_add(rr[set][0][h], rr[set][1][h]);
+      else a2[set][h] = pk_sub(rr[set][0][h], rr[set][1][h]);
+    }
   };
-  auto addr_d = [&]() {
-    PIN(tx_);
-    const int y0 = 2 * ty_ - 1, x0 = 2 * tx_ - 1;
-    xb_ = ((n_ * p.H + y0) * p.W + x0) * xs4 + q16;
-    yb_ = ((n_ * p.H + 2 * ty_) * p.W + 2 * tx_) * ys4 + q16;
-    PIN(xb_);
-    PIN(yb_);
+  auto xform_all = [&](auto setc) {
+    xform(setc, ic<0>{}); xform(setc, ic<1>{}); xform(setc, ic<2>{}); xform(setc, ic<3>{}); xform(setc, ic<4>{}); xform(setc, ic<5>{});
+    xform(setc, ic<6>{}); xform(setc, ic<7>{}); xform(setc, ic<8>{}); xform(setc, ic<9>{}); xform(setc, ic<10>{}); xform(setc, ic<11>{});
+    xform(setc, ic<12>{}); xform(setc, ic<13>{}); xform(setc, ic<14>{}); xform(setc, ic<15>{}); xform(setc, ic<16>{}); xform(setc, ic<17>{});
+    xform(setc, ic<18>{}); xform(setc, ic<19>{}); xform(setc, ic<20>{}); xform(setc, ic<21>{}); xform(setc, ic<22>{}); xform(setc, ic<23>{});
   };
-  auto load_x = [&](auto setc, auto rc, auto cc) {
-    constexpr int set = decltype(setc)::value, r = decltype(rc)::value, c = decltype(cc)::value;
-    const int rr = r ? rB : rA;
-    const bool ok = (r ? okB_ : okA_) && (unsigned)(2 * tx_ - 1 + c) < (unsigned)p.W;
-    rx[set][r][c] = buf_load16(rsx, ok ? (unsigned)(xb_ + (rr * p.W + c) * xs4) : kOob, 0);
+  auto load_px_all = [&](auto setc, auto ts) {
+    load_px(setc, ts, ic<0>{}); load_px(setc, ts, ic<1>{}); load_px(setc, ts, ic<2>{}); load_px(setc, ts, ic<3>{});
+    load_px(setc, ts, ic<4>{}); load_px(setc, ts, ic<5>{}); load_px(setc, ts, ic<6>{}); load_px(setc, ts, ic<7>{});
+    load_px(setc, ts, ic<8>{}); load_px(setc, ts, ic<9>{}); load_px(setc, ts, ic<10>{}); load_px(setc, ts, ic<11>{});
   };
-  auto load_y = [&](auto setc, auto rc, auto cc) {
-    constexpr int set = decltype(setc)::value, r = decltype(rc)::value, c = decltype(cc)::value;
-    const bool ok = (r ? ok1_ : ok0_) && (c == 0 || 2 * tx_ + 1 < p.W);
-    ry[set][r][c] = buf_load16(rsy, ok ? (unsigned)(yb_ + (r * p.W + c) * ys4) : kOob, 0);
-  };
-  // ---- transforms: raw set -> operand set ---------------------------------------------------------------------------
-  f32x4 v_[4], r_[2];
-  auto xf_row = [&](auto setc, auto cc) {             // v[c] = x[rA][c] + sB x[rB][c]
-    constexpr int set = decltype(setc)::value, c = decltype(cc)::value;
-    PIN(rx[set][0][c]);
-    PIN(rx[set][1][c]);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v_[c][e] = fmaf(sB, rx[set][1][c][e], rx[set][0][c][e]);
-    PIN(v_[c]);
-  };
-  auto xf_col = [&](auto setc, auto fc_) {            // B^T applied along the columns
-    constexpr int set = decltype(setc)::value, fc = decltype(fc_)::value;
-    if constexpr (fc == 0) { PIN(v_[0]); bo[set][0] = v_[0] - v_[2]; PIN(bo[set][0]); }
-    if constexpr (fc == 1) { PIN(v_[2]); bo[set][1] = v_[1] + v_[2]; PIN(bo[set][1]); }
-    if constexpr (fc == 2) { PIN(v_[1]); bo[set][2] = v_[2] - v_[1]; PIN(bo[set][2]); }
-    if constexpr (fc == 3) { PIN(v_[3]); bo[set][3] = v_[1] - v_[3]; PIN(bo[set][3]); }
-  };
-  auto yf_row = [&](auto setc, auto cc) {             // r[c] = cA dy[0][c] + cB dy[1][c]
-    constexpr int set = decltype(setc)::value, c = decltype(cc)::value;
-    PIN(ry[set][0][c]);
-    PIN(ry[set][1][c]);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) r_[c][e] = fmaf(cB, ry[set][1][c][e], cA * ry[set][0][c][e]);
-    PIN(r_[c]);
-  };
-  auto yf_col = [&](auto setc, auto fc_) {            // A applied along the columns: r0, r0 + r1, r0 - r1, -r1
-    constexpr int set = decltype(setc)::value, fc = decltype(fc_)::value;
-    if constexpr (fc == 0) { PIN(r_[0]); ao[set][0] = r_[0]; PIN(ao[set][0]); }
-    if constexpr (fc == 1) { PIN(r_[1]); ao[set][1] = r_[0] + r_[1]; PIN(ao[set][1]); }
-    if constexpr (fc == 2) { PIN(r_[0]); ao[set][2] = r_[0] - r_[1]; PIN(ao[set][2]); }
-    if constexpr (fc == 3) { PIN(r_[1]); ao[set][3] = -r_[1]; PIN(ao[set][3]); }
-  };
-  auto load_all = [&](auto setc, int s) {
-    addr_a(s);
-    addr_b();
-    addr_c(s);
-    addr_d();
-    load_x(setc, ic<0>{}, ic<0>{}); load_x(setc, ic<0>{}, ic<1>{}); load_x(setc, ic<0>{}, ic<2>{}); load_x(setc, ic<0>{}, ic<3>{});
-    load_x(setc, ic<1>{}, ic<0>{}); load_x(setc, ic<1>{}, ic<1>{}); load_x(setc, ic<1>{}, ic<2>{}); load_x(setc, ic<1>{}, ic<3>{});
-    load_y(setc, ic<0>{}, ic<0>{}); load_y(setc, ic<0>{}, ic<1>{}); load_y(setc, ic<1>{}, ic<0>{}); load_y(setc, ic<1>{}, ic<1>{});
-  };
-  auto transform_all = [&](auto setc) {
-    xf_row(setc, ic<0>{}); xf_row(setc, ic<1>{}); xf_row(setc, ic<2>{}); xf_row(setc, ic<3>{});
-    xf_col(setc, ic<0>{}); xf_col(setc, ic<1>{}); xf_col(setc, ic<2>{}); xf_col(setc, ic<3>{});
-    yf_row(setc, ic<0>{}); yf_row(setc, ic<1>{});
-    yf_col(setc, ic<0>{}); yf_col(setc, ic<1>{}); yf_col(setc, ic<2>{}); yf_col(setc, ic<3>{});
-  };
+  auto load_tab_all = [&](auto setc, int s) { load_tab(setc, s, ic<0>{}); load_tab(setc, s, ic<1>{}); load_tab(setc, s, ic<2>{}); };
 
-  // ---- one k-step: 64 MFMAs on operand set CUR; in their shadow the loads of step s+2 (into raw set CUR, whose data
-  //      became operand set CUR during step s-1) and the transform of raw set CUR^1 (step s+1) into operand set CUR^1 ---
+  // ---- one k-step: 64 MFMAs on operand set CUR; in their gaps the table entries of step s+3 (into table set CUR), the
+  //      pixels of step s+2 (entries in table set CUR^1, fetched during step s-1) into raw set CUR, and the transform of
+  //      raw set CUR^1 (step s+1, loaded during step s-1) into operand set CUR^1 ---------------------------------------
   auto step = [&](auto curc, int s) {
     constexpr int cur = decltype(curc)::value, nxt = cur ^ 1;
     const ic<cur> CS{};
@@ -184,49 +212,65 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_f32(const WwArgs p) {
 #pragma unroll
         for (int ib = 0; ib < 4; ++ib) {
           const int m = fc * 16 + cb * 4 + ib;
-          MFMA(acc[fc][cb][ib], ao[cur][fc][cb], bo[cur][fc][ib]);
-          if (m == 0) addr_a(s + 2);
-          if (m == 1) addr_b();
-          if (m == 2) addr_c(s + 2);
-          if (m == 3) addr_d();
-          if (m == 4) load_x(CS, ic<0>{}, ic<0>{});
-          if (m == 5) load_x(CS, ic<0>{}, ic<1>{});
-          if (m == 6) load_x(CS, ic<0>{}, ic<2>{});
-          if (m == 7) load_x(CS, ic<0>{}, ic<3>{});
-          if (m == 8) load_x(CS, ic<1>{}, ic<0>{});
-          if (m == 9) load_x(CS, ic<1>{}, ic<1>{});
-          if (m == 10) load_x(CS, ic<1>{}, ic<2>{});
-          if (m == 11) load_x(CS, ic<1>{}, ic<3>{});
-          if (m == 12) load_y(CS, ic<0>{}, ic<0>{});
-          if (m == 13) load_y(CS, ic<0>{}, ic<1>{});
-          if (m == 14) load_y(CS, ic<1>{}, ic<0>{});
-          if (m == 15) load_y(CS, ic<1>{}, ic<1>{});
-          if (m == 32) xf_row(NS, ic<0>{});
-          if (m == 33) xf_row(NS, ic<1>{});
-          if (m == 34) xf_row(NS, ic<2>{});
-          if (m == 35) xf_row(NS, ic<3>{});
-          if (m == 36) xf_col(NS, ic<0>{});
-          if (m == 37) xf_col(NS, ic<1>{});
-          if (m == 38) xf_col(NS, ic<2>{});
-          if (m == 39) xf_col(NS, ic<3>{});
-          if (m == 40) yf_row(NS, ic<0>{});
-          if (m == 41) yf_row(NS, ic<1>{});
-          if (m == 42) yf_col(NS, ic<0>{});
-          if (m == 43) yf_col(NS, ic<1>{});
-          if (m == 44) yf_col(NS, ic<2>{});
-          if (m == 45) yf_col(NS, ic<3>{});
+          const float a = fc == 0 ? rr[cur][0][cb >> 1][cb & 1] : fc == 1 ? a1[cur][cb >> 1][cb & 1]
+                        : fc == 2 ? a2[cur][cb >> 1][cb & 1] : rr[cur][1][cb >> 1][cb & 1];
+          MFMA(acc[fc][cb][ib], a, bo[cur][fc][ib >> 1][ib & 1]);
+          if (m == 0) load_tab(CS, s + 3, ic<0>{});
+          if (m == 1) load_tab(CS, s + 3, ic<1>{});
+          if (m == 2) load_tab(CS, s + 3, ic<2>{});
+          if (m == 3) load_px(CS, NS, ic<0>{});
+          if (m == 4) load_px(CS, NS, ic<1>{});
+          if (m == 5) load_px(CS, NS, ic<2>{});
+          if (m == 6) load_px(CS, NS, ic<3>{});
+          if (m == 7) load_px(CS, NS, ic<4>{});
+          if (m == 8) load_px(CS, NS, ic<5>{});
+          if (m == 9) load_px(CS, NS, ic<6>{});
+          if (m == 10) load_px(CS, NS, ic<7>{});
+          if (m == 11) load_px(CS, NS, ic<8>{});
+          if (m == 12) load_px(CS, NS, ic<9>{});
+          if (m == 13) load_px(CS, NS, ic<10>{});
+          if (m == 14) load_px(CS, NS, ic<11>{});
+          if (m == 38) xform(NS, ic<0>{});
+          if (m == 39) xform(NS, ic<1>{});
+          if (m == 40) xform(NS, ic<2>{});
+          if (m == 41) xform(NS, ic<3>{});
+          if (m == 42) xform(NS, ic<4>{});
+          if (m == 43) xform(NS, ic<5>{});
+          if (m == 44) xform(NS, ic<6>{});
+          if (m == 45) xform(NS, ic<7>{});
+          if (m == 46) xform(NS, ic<8>{});
+          if (m == 47) xform(NS, ic<9>{});
+          if (m == 48) xform(NS, ic<10>{});
+          if (m == 49) xform(NS, ic<11>{});
+          if (m == 50) xform(NS, ic<12>{});
+          if (m == 51) xform(NS, ic<13>{});
+          if (m == 52) xform(NS, ic<14>{});
+          if (m == 53) xform(NS, ic<15>{});
+          if (m == 54) xform(NS, ic<16>{});
+          if (m == 55) xform(NS, ic<17>{});
+          if (m == 56) xform(NS, ic<18>{});
+          if (m == 57) xform(NS, ic<19>{});
+          if (m == 58) xform(NS, ic<20>{});
+          if (m == 59) xform(NS, ic<21>{});
+          if (m == 60) xform(NS, ic<22>{});
+          if (m == 61) xform(NS, ic<23>{});
           __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
   };
 
-  load_all(ic<0>{}, s_begin);
-  load_all(ic<1>{}, s_begin + 1);
-  transform_all(ic<0>{});
+  // (issue order as in the steady state -- table entries of a step before the pixels of the step before it -- so that the
+  //  s_waitcnt counts hipcc derives for the loop head are the exact ones of the loop body)
+  load_tab_all(ic<0>{}, s_begin);
+  load_px_all(ic<0>{}, ic<0>{});
+  load_tab_all(ic<0>{}, s_begin + 1);
+  load_tab_all(ic<1>{}, s_begin + 2);
+  load_px_all(ic<1>{}, ic<0>{});
+  xform_all(ic<0>{});
   asm volatile("s_nop 7");                            // accumulator zeros / first operands written by the VALU: keep clear of the MFMA
-  for (int s = s_begin; s < s_end; s += 2) {          // an odd count runs one dead step: its loads are all out of range, it adds zeros
-    step(ic<0>{}, s);
+  for (int s = s_begin; s < s_end; s += 2) {          // steps run in pairs (steps_per_split is even; past the last tile the table
+    step(ic<0>{}, s);                                 // holds only out-of-range offsets: a dead step adds zeros)
     step(ic<1>{}, s + 1);
   }
   asm volatile("s_nop 15\n\ts_nop 15");               // last MFMA results land before the accumulators are read
@@ -286,7 +330,8 @@ __global__ __launch_bounds__(256) void wino_wgrad_final(const float* __restrict_
   if (tid < 144) {
     const int tap = tid >> 4, a = tap / 3, b = tap - 3 * a;        // c4 = tid & 15 as above
     // column b of G per g, column a of G per f
-    const float gb[4] = {b == 0 ? 1.f : 0.f, 0.5f, b == 1 ? -0.5f : 0.5f, b == 2 ? 1.f : 0.f};
+    // (frequency column 3 of A dY A^T is accumulated with the opposite sign: the main kernel feeds +dY where A has -1)
+    const float gb[4] = {b == 0 ? 1.f : 0.f, 0.5f, b == 1 ? -0.5f : 0.5f, b == 2 ? -1.f : 0.f};
     const float ga[4] = {a == 0 ? 1.f : 0.f, 0.5f, a == 1 ? -0.5f : 0.5f, a == 2 ? 1.f : 0.f};
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -312,7 +357,7 @@ bool ww_plan(int N, int H, int W, int Cin, int Cout, WwPlan* pl) {
   pl->tilesX = (W + 1) / 2;
   pl->tilesY = (H + 1) / 2;
   const long long T = (long long)N * pl->tilesY * pl->tilesX;
-  if ((T + 8) * pl->tilesX >= (1ll << 32) || T + 8 >= (1ll << 30)) return false;     // umulhi division stays exact
+  if ((T + 32) * TE_BYTES >= (1ll << 31)) return false;                               // the table is read with 32-bit offsets
   pl->T = (int)T;
   pl->steps = (int)((T + 3) / 4);
   pl->nci = Cin / 64;
@@ -336,8 +381,27 @@ extern "C" size_t bevf_wino_wgrad_workspace_floats(int N, int H, int W, int Cin,
   return ((size_t)pl.splits + groups) * 16 * Cout * Cin;
 }
 
+extern "C" size_t bevf_wino_wgrad_table_bytes(int N, int H, int W) {
+  WwPlan pl;
+  if (!ww_plan(N, H, W, 64, 64, &pl)) return 0;
+  return (size_t)4 * (pl.steps + 4) * TE_BYTES;
+}
+
+extern "C" int bevf_wino_wgrad_table(int32_t* tab, int N, int H, int W, int x_cs, int dy_cs, void* stream) {
+  WwPlan pl;
+  BEVF_REQUIRE(tab && ww_plan(N, H, W, 64, 64, &pl), "wino wgrad table: bad shape N=%d H=%d W=%d", N, H, W);
+  BEVF_REQUIRE(x_cs > 0 && dy_cs > 0 && x_cs % 4 == 0 && dy_cs % 4 == 0, "wino wgrad table: channel strides must be multiples of 4");
+  BEVF_REQUIRE((long long)N * H * W * x_cs * 4 < (1ll << 31) && (long long)N * H * W * dy_cs * 4 < (1ll << 31),
+               "wino wgrad table: x / dy buffers must stay below 2 GiB (32-bit buffer offsets)");
+  BEVF_REQUIRE(bevf_aligned16(tab), "wino wgrad table: unaligned");
+  const int Tpad = 4 * (pl.steps + 4);
+  hipLaunchKernelGGL(wino_wgrad_table, dim3((Tpad + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), tab, H, W,
+                     pl.tilesX, pl.tilesY, pl.T, Tpad, x_cs * 4, dy_cs * 4);
+  return bevf_check_launch("bevf_wino_wgrad_table");
+}
+
 extern "C" int bevf_conv3x3_wgrad_wino_f32(const bevf_wgrad_desc* d, float* workspace, int accumulate, void* stream) {
-  BEVF_REQUIRE(d && d->x && d->dy && d->dw && workspace, "wino wgrad: null pointer");
+  BEVF_REQUIRE(d && d->x && d->dy && d->dw && d->pixtab && workspace, "wino wgrad: null pointer (pixtab = bevf_wino_wgrad_table)");
   BEVF_REQUIRE(d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1, "wino wgrad: 3x3 / stride 1 / pad 1 only");
   WwPlan pl;
   BEVF_REQUIRE(ww_plan(d->N, d->H, d->W, d->Cin, d->Cout, &pl),
@@ -345,16 +409,13 @@ extern "C" int bevf_conv3x3_wgrad_wino_f32(const bevf_wgrad_desc* d, float* work
                "bevf_wino_wgrad_workspace_floats returns 0 for these)", d->N, d->H, d->W, d->Cin, d->Cout);
   BEVF_REQUIRE(d->x_cs >= d->Cin && d->x_cs % 4 == 0 && d->dy_cs >= d->Cout && d->dy_cs % 4 == 0,
                "wino wgrad: channel strides must be multiples of 4 and cover the channels");
-  BEVF_REQUIRE(bevf_aligned16(d->x) && bevf_aligned16(d->dy) && bevf_aligned16(d->dw) && bevf_aligned16(workspace),
+  BEVF_REQUIRE(bevf_aligned16(d->x) && bevf_aligned16(d->dy) && bevf_aligned16(d->dw) && bevf_aligned16(workspace) && bevf_aligned16(d->pixtab),
                "wino wgrad: unaligned");
   BEVF_REQUIRE((long long)d->N * d->H * d->W * d->x_cs * 4 < (1ll << 31) && (long long)d->N * d->H * d->W * d->dy_cs * 4 < (1ll << 31),
                "wino wgrad: x / dy buffers must stay below 2 GiB (32-bit buffer offsets)");
   WwArgs a;
-  a.x = d->x; a.dy = d->dy; a.part = workspace;
-  a.H = d->H; a.W = d->W; a.x_cs = d->x_cs; a.dy_cs = d->dy_cs; a.Cin = d->Cin; a.Cout = d->Cout;
-  a.tilesX = pl.tilesX; a.tilesY = pl.tilesY; a.T = pl.T;
-  a.mX = (unsigned)((1ull << 32) / (unsigned)pl.tilesX) + 1u;
-  a.mY = (unsigned)((1ull << 32) / (unsigned)pl.tilesY) + 1u;
+  a.x = d->x; a.dy = d->dy; a.tab = d->pixtab; a.part = workspace;
+  a.Cin = d->Cin; a.Cout = d->Cout;
   a.steps = pl.steps; a.steps_per_split = pl.steps_per_split; a.nci = pl.nci; a.nco = pl.nco;
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(wino_wgrad_f32, dim3(pl.splits * pl.nci * pl.nco), dim3(256), 0, st, a);

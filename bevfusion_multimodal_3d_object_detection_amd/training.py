@@ -79,6 +79,17 @@ def _pixtab(N, H, W, k, stride, pad, x_cs, dev) -> torch.Tensor:
     return t
 
 
+def _wino_wgrad_table(N, H, W, x_cs, dy_cs, dev) -> torch.Tensor:
+    """Per-shape tile table of the Winograd weight gradient (pixel byte offsets per 2x2 tile), cached like _pixtab."""
+    key = ("wwtab", N, H, W, x_cs, dy_cs, str(dev))
+    t = _PIXTAB.get(key)
+    if t is None:
+        t = torch.empty(_lib().bevf_wino_wgrad_table_bytes(N, H, W) // 4, dtype=torch.int32, device=dev)
+        _ck(_lib().bevf_wino_wgrad_table(t.data_ptr(), N, H, W, x_cs, dy_cs, _st()), "bevf_wino_wgrad_table")
+        _PIXTAB[key] = t
+    return t
+
+
 # ---- primitive ops (thin wrappers over the C-ABI; all tensors fp32 cuda, flat NHWC) ---------------------------------
 
 # The conv kernels address their operands with 32-bit byte offsets: a tensor handed to one launch must stay below
@@ -158,7 +169,8 @@ def conv_wgrad(x, dy, N, H, W, cin, cout, k, stride, pad, dw=None) -> torch.Tens
     if ws:
         if fresh:
             dw = _new(cout * 9 * cin, x.device)
-        d = L.WgradDesc(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, N, H, W, cin, cin, cout, cout, 3, 3, 1, 1)
+        d = L.WgradDesc(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _wino_wgrad_table(N, H, W, cin, cout, x.device).data_ptr(),
+                        N, H, W, cin, cin, cout, cout, 3, 3, 1, 1)
         work = _new(ws, x.device)
         with E._span("conv_wgrad_wino_f32", flops=flops):
             _ck(_lib().bevf_conv3x3_wgrad_wino_f32(C.byref(d), work.data_ptr(), 0 if fresh else 1, _st()),

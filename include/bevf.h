@@ -352,8 +352,12 @@ int bevf_conv2d_wgrad_f32(const bevf_wgrad_desc* d, void* stream);
 /* The same gradient for 3x3 / stride 1 / pad 1 layers with Cin, Cout multiples of 64, in the Winograd F(2x2,3x3) domain
  * (csrc/conv_wino_wgrad.hip): 2.25x fewer MFMA FLOPs, deterministic (fixed-order sum of per-workgroup partial blocks, no
  * atomics).  `workspace`: bevf_wino_wgrad_workspace_floats() floats (0 = shape not supported: use bevf_conv2d_wgrad_f32);
- * `pixtab` of the descriptor is not used; accumulate != 0 adds to dw instead of overwriting it.  dw: [Cout][3][3][Cin]. */
+ * `pixtab` of the descriptor = the per-shape tile table written by bevf_wino_wgrad_table (bevf_wino_wgrad_table_bytes()
+ * bytes; depends on N, H, W and the two channel strides only, reusable across layers and steps); accumulate != 0 adds to
+ * dw instead of overwriting it.  dw: [Cout][3][3][Cin]. */
 size_t bevf_wino_wgrad_workspace_floats(int N, int H, int W, int Cin, int Cout);
+size_t bevf_wino_wgrad_table_bytes(int N, int H, int W);
+int bevf_wino_wgrad_table(int32_t* tab, int N, int H, int W, int x_cs, int dy_cs, void* stream);
 int bevf_conv3x3_wgrad_wino_f32(const bevf_wgrad_desc* d, float* workspace, int accumulate, void* stream);
 
 /* Data gradient: the forward kernel (bevf_conv2d_nhwc_f32) run on dy with the spatially flipped, channel-

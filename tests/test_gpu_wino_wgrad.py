@@ -82,11 +82,15 @@ def test_wino_wgrad_refuses_what_it_cannot_do(gpu):
     x = torch.zeros(2 * 9 * 13 * 64, device="cuda")
     dw = torch.zeros(64 * 9 * 64, device="cuda")
     work = torch.zeros(1 << 20, device="cuda")
-    d = L.WgradDesc(x.data_ptr(), x.data_ptr(), dw.data_ptr(), None, 2, 9, 13, 32, 32, 64, 64, 3, 3, 1, 1)
+    tab = training._wino_wgrad_table(2, 9, 13, 64, 64, x.device)
+    d = L.WgradDesc(x.data_ptr(), x.data_ptr(), dw.data_ptr(), tab.data_ptr(), 2, 9, 13, 32, 32, 64, 64, 3, 3, 1, 1)
     assert lib.bevf_conv3x3_wgrad_wino_f32(C.byref(d), work.data_ptr(), 0, None) != 0
     assert b"unsupported shape" in lib.bevf_last_error()
-    d = L.WgradDesc(x.data_ptr(), x.data_ptr(), dw.data_ptr(), None, 2, 9, 13, 64, 64, 64, 64, 3, 3, 2, 1)
+    d = L.WgradDesc(x.data_ptr(), x.data_ptr(), dw.data_ptr(), tab.data_ptr(), 2, 9, 13, 64, 64, 64, 64, 3, 3, 2, 1)
     assert lib.bevf_conv3x3_wgrad_wino_f32(C.byref(d), work.data_ptr(), 0, None) != 0
+    d = L.WgradDesc(x.data_ptr(), x.data_ptr(), dw.data_ptr(), None, 2, 9, 13, 64, 64, 64, 64, 3, 3, 1, 1)        # no tile table
+    assert lib.bevf_conv3x3_wgrad_wino_f32(C.byref(d), work.data_ptr(), 0, None) != 0
+    assert lib.bevf_wino_wgrad_table_bytes(2, 2, 13) == 0
     # the host wrapper routes such layers to the pixel-GEMM kernel
     xs, dys = synth.normal((2, 32, 9, 13), 41), synth.normal((2, 64, 9, 13), 42)
     w = torch.zeros(64, 32, 3, 3, requires_grad=True)
