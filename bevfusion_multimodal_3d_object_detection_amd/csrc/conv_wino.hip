@@ -52,7 +52,9 @@ struct WinoArgs {
 };
 
 constexpr int PIX = 18 * 18, PITCH = 36;                       // patch pixels, floats per pixel in LDS (32 + 4 pad)
-constexpr int PATCH_FLOATS = PIX * PITCH;                      // 11664 floats = 46656 B
+constexpr int PSLOTS = PIX * 9;                                // 16-byte slots of a patch chunk: 8 data + 1 pad per pixel
+constexpr int PDMA = 12;                                       // LDS-DMA instructions per wave and chunk (4 waves x 12 x 64 slots)
+constexpr int PATCH_FLOATS = 4 * PDMA * 64 * 4;                // 12288 floats = 48 KiB: the 2916 slots rounded up to 48 x 64
 constexpr int BG_FLOATS = 16 * 4 * 16 * 8;                     // 8192 floats = 32 KB per channel group
 constexpr int LDS_BYTES = (2 * PATCH_FLOATS + 2 * BG_FLOATS) * 4;
 
@@ -67,10 +69,11 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
   const int NCH = p.Cin >> 5;                                   // patch chunks of 32 channels
   const int nsp = p.N * p.TBY * p.TBX, ntiles = nsp * p.nct;    // tile index = ct * nsp + spatial: concurrent workgroups share
                                                                 // one 64-channel slab of transformed filters (L2-resident)
-  // ---- patch staging role: slot s = tid + 256 i -> pixel s>>3, 16-byte piece s&7 ---------------------------------
+  // ---- patch staging by LDS-DMA (buffer_load ... lds: an out-of-range lane writes zeros -- the pad ring, the pad slot of
+  //      every pixel, the slots past the patch): instruction (4 j + wave), j < 12, fills 64 consecutive 16-byte slots;
+  //      slot s = pixel s / 9, piece s % 9 (8 = pad) --------------------------------------------------------------------
   const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)kOob, 0x00020000);
-  const int sl4 = 4 * (tid & 7);
-  auto make_pv = [&](int tile, unsigned (&pv)[11], int& n, int& by, int& bx, int& ct) {
+  auto make_pv = [&](int tile, unsigned (&pv)[PDMA], int& n, int& by, int& bx, int& ct) {
     ct = tile / nsp;
     int sp = tile - ct * nsp;
     bx = sp % p.TBX;
@@ -80,21 +83,28 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
     const int iy0 = 16 * by - 1, ix0 = 16 * bx - 1;
     const bool live = tile < ntiles;
 #pragma unroll
-    for (int i = 0; i < 11; ++i) {
-      const int pix = (tid >> 3) + 32 * i, py = (pix * 3641) >> 16, px = pix - py * 18;      // pix / 18 for pix < 1024
+    for (int j = 0; j < PDMA; ++j) {
+      const int sl = (4 * j + wave) * 64 + lane;
+      const int pix = (sl * 7282) >> 16, piece = sl - 9 * pix;                                  // sl / 9 for sl < 3072
+      const int py = (pix * 3641) >> 16, px = pix - py * 18;                                    // pix / 18 for pix < 1024
       const int iy = iy0 + py, ix = ix0 + px;
-      const bool ok = live && pix < PIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      pv[i] = ok ? (unsigned)((((n * p.H + iy) * p.W + ix) * p.x_cs + sl4) * 4) : kOob;
+      const bool ok = live && sl < PSLOTS && piece < 8 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      pv[j] = ok ? (unsigned)((((n * p.H + iy) * p.W + ix) * p.x_cs + 4 * piece) * 4) : kOob;
     }
   };
-  const int pw_off = (tid >> 3) * PITCH + sl4;                  // floats; + i * 32 * PITCH
-  const bool last_ok = tid < (PIX * 8 - 2560);                  // slot i = 10 exists for 32 threads only
+  auto patch_dma = [&](unsigned voff, unsigned soff, int buf, int j) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(patch + buf * PATCH_FLOATS + (4 * j + wave) * 256),
+                                             16, voff, soff, 0, 0);
+  };
 
   // ---- B staging by LDS-DMA: group image = 32 pieces of 1 KiB; wave w issues pieces 8w .. 8w+7 ----------------------
-  const float* const ub = p.u + (size_t)wave * 8 * 256 + lane * 4;
-  auto dma_piece = [&](const float* src, int buf, int i) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 256),
-                                     (__attribute__((address_space(3))) void*)(bbuf + buf * BG_FLOATS + wave * 8 * 256 + i * 256), 16, 0, 0);
+  // (buffer form: the per-lane part of the address is one constant VGPR, the image / piece offset a scalar -- the global
+  //  form cost a 64-bit vector add per piece, and the fp32 MFMA shares the vector ALU)
+  const __amdgpu_buffer_rsrc_t rsu = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, (int)kOob, 0x00020000);
+  const unsigned u_lane = (unsigned)((wave * 8 * 256 + lane * 4) * 4);
+  auto dma_piece = [&](unsigned img, int buf, int i) {              // img: byte offset of the group image in p.u
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (__attribute__((address_space(3))) void*)(bbuf + buf * BG_FLOATS + wave * 8 * 256 + i * 256),
+                                             16, u_lane, img + i * 1024, 0, 0);
   };
 
   // ---- compute roles --------------------------------------------------------------------------------------------
@@ -123,22 +133,25 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
 
   // ---- prologue: first tile's patch chunk 0, B group 0, A fragments of group 0 -----------------------------------------
   int tile = blockIdx.x;
-  unsigned pv[11], pvl[11];
+  unsigned pv[PDMA], pvl[PDMA];
   int n, by, bx, ct;
   {                                                                 // filter DMA first: it flies while the slot offsets are computed
     const int ct0 = tile / nsp;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dma_piece(ub + (size_t)ct0 * G * BG_FLOATS, 0, i);
+    for (int i = 0; i < 8; ++i) dma_piece((unsigned)(ct0 * G) * (BG_FLOATS * 4), 0, i);
   }
   make_pv(tile, pv, n, by, bx, ct);
-  {
-    f32x4 r[11];
 #pragma unroll
-    for (int i = 0; i < 11; ++i) r[i] = buf_load16(rsx, pv[i], 0);
+  for (int j = 0; j < PDMA; ++j) patch_dma(pv[j], 0, 0, j);
+  // Staging schedule (filter image of group g+1 and a third of a later patch chunk per group, everything by LDS-DMA, no
+  // register staging and no ds_write in the loop): chunk c+1's patch is fetched in three parts, in the last group of
+  // chunk c-1 and groups 0, 1 of chunk c, always AFTER the group's filter pieces.  Loads retire in order, so the
+  // hand-written wait at a group's end, vmcnt(4), names exactly the filter image and leaves the newest patch part in
+  // flight: every patch load has at least a whole group (1.7 us) to land.  (A __syncthreads() waits vmcnt(0), and hipcc
+  // adds vmcnt(0) before any ds_write that follows an LDS-DMA: in-kernel ablation put 13 % of the kernel on those waits.)
 #pragma unroll
-    for (int i = 0; i < 10; ++i) *reinterpret_cast<f32x4*>(patch + pw_off + i * 32 * PITCH) = r[i];
-    if (last_ok) *reinterpret_cast<f32x4*>(patch + pw_off + 10 * 32 * PITCH) = r[10];
-  }
+  for (int j = 0; j < 4; ++j) patch_dma(NCH > 1 ? pv[j] : kOob, 128, 1, j);
+  asm volatile("s_waitcnt vmcnt(4)");
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < 4; ++q) load_patch(0, 0, q);
@@ -150,13 +163,12 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
 
   // one channel group (8 channels = 2 MFMA k-steps); gl = position in the 32-channel patch chunk (static)
   //   pvl / psoff: where the NEXT chunk's patch comes from (this tile's next chunk, or the next tile's chunk 0)
-  //   bsrc: the NEXT group's filter image (null: nothing follows)
-  auto group = [&](auto glc, auto firstc, const unsigned psoff, const float* bsrc) {
+  //   bimg: byte offset of the NEXT group's filter image in p.u (bnext false: nothing follows)
+  auto group = [&](auto glc, auto firstc, const unsigned psoff, const unsigned bimg, const bool bnext) {
     constexpr int gl = decltype(glc)::value;
     constexpr bool kFirst = decltype(firstc)::value;      // a tile's first group: its k-step-0 MFMAs start the accumulators (C = 0)
     const int abuf = gl == 3 ? pbuf ^ 1 : pbuf;                     // A fragments of the next group: next chunk after gl 3
     constexpr int agl = (gl + 1) & 3;
-    f32x4 rr[4];
     const float* pb = bbuf + (gl & 1) * BG_FLOATS + b_lane;
     const float* pa = patch + abuf * PATCH_FLOATS + a_lane + agl * 8;
     f32x4 b0[2], b1[2];
@@ -191,19 +203,19 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
           if (k == 2) { v[4 * r + 0] = dn[4 * r + 0] - dn[4 * r + 2]; v[4 * r + 1] = dn[4 * r + 1] + dn[4 * r + 2]; }
           if (k == 3) { v[4 * r + 2] = dn[4 * r + 2] - dn[4 * r + 1]; v[4 * r + 3] = dn[4 * r + 1] - dn[4 * r + 3]; }
         }
-        // staging: patch loads early, filter DMA in the first half of the group, LDS writes late
-        if (k == 5 && gl < 3 && (f & 1) == 0 && f < 8 && gl * 4 + (f >> 1) < 11) rr[f >> 1] = buf_load16(rsx, pvl[gl * 4 + (f >> 1)], psoff);
-        if (k == 6 && f < 8 && bsrc) dma_piece(bsrc, (gl + 1) & 1, f);
-        if (k == 5 && gl < 3 && (f & 1) == 0 && f >= 8) {
-          const int i = (f - 8) >> 1;
-          float* pd = patch + (pbuf ^ 1) * PATCH_FLOATS + pw_off + (gl * 4 + i) * 32 * PITCH;
-          if (gl * 4 + i < 10) *reinterpret_cast<f32x4*>(pd) = rr[i];
-          else if (gl * 4 + i == 10) { if (last_ok) *reinterpret_cast<f32x4*>(pd) = rr[i]; }
+        // staging: the next group's filter image first, then this group's part of a later patch chunk (see above)
+        if (f == 0 && bnext) dma_piece(bimg, (gl + 1) & 1, k);
+        if (f == 1 && k >= 4 && gl != 2) {
+          constexpr int part = gl == 3 ? 0 : gl + 1;
+          patch_dma(pvl[part * 4 + (k - 4)], psoff, gl == 3 ? pbuf : pbuf ^ 1, part * 4 + (k - 4));
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    __syncthreads();
+    // group end: the filter image (and, after group 2, the whole next patch chunk) has landed; the patch part issued in
+    // this group stays in flight.  Wait and barrier are ONE asm with a memory clobber (no LDS access moves across it):
+    // through __syncthreads() or a workgroup fence hipcc waits vmcnt(0) here, the DMA being an LDS write to it.
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(gl == 2 ? 0 : 4) : "memory");
   };
   using G0 = std::integral_constant<int, 0>;
   using G1 = std::integral_constant<int, 1>;
@@ -214,22 +226,27 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
     using T = std::true_type;
     using F = std::false_type;
 #pragma unroll
-    for (int i = 0; i < 11; ++i) pvl[i] = pv[i];
+    for (int j = 0; j < PDMA; ++j) pvl[j] = pv[j];
     for (int chunk = 0; chunk < NCH; ++chunk) {                     // 32 channels
       const bool lastc = chunk + 1 == NCH;
-      const float* ug = ub + ((size_t)ct * G + chunk * 4) * BG_FLOATS;
+      const unsigned ug = (unsigned)(ct * G + chunk * 4) * (BG_FLOATS * 4), gb = BG_FLOATS * 4;
       const unsigned soff = (unsigned)((chunk + 1) * 128);
-      if (lastc) {                                                  // nothing follows: out-of-range VGPR offsets, the loads return
-#pragma unroll                                                      // zeros without touching memory (the SGPR offset is not range-checked)
-        for (int i = 0; i < 11; ++i) pvl[i] = kOob;
+      if (lastc) {                                                  // no next chunk: out-of-range VGPR offsets, the DMA writes zeros
+#pragma unroll                                                      // into the idle buffer (the SGPR offset is not range-checked)
+        for (int j = 4; j < PDMA; ++j) pvl[j] = kOob;
       }
-      if (chunk == 0) group(G0{}, T{}, soff, ug + 1 * BG_FLOATS); else group(G0{}, F{}, soff, ug + 1 * BG_FLOATS);
-      group(G1{}, F{}, soff, ug + 2 * BG_FLOATS);
-      group(G2{}, F{}, soff, ug + 3 * BG_FLOATS);
-      group(G3{}, F{}, soff, lastc ? nullptr : ug + 4 * BG_FLOATS);
+      if (chunk + 2 >= NCH) {                                       // no chunk after next: the same for the part group 3 fetches
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pvl[j] = kOob;
+      }
+      if (chunk == 0) group(G0{}, T{}, soff, ug + 1 * gb, true); else group(G0{}, F{}, soff, ug + 1 * gb, true);
+      group(G1{}, F{}, soff, ug + 2 * gb, true);
+      group(G2{}, F{}, soff, ug + 3 * gb, true);
+      group(G3{}, F{}, soff + 128, ug + 4 * gb, !lastc);
       pbuf ^= 1;
     }
 
+    asm volatile("s_waitcnt vmcnt(0)");                             // (the last, all-out-of-range patch part: LDS is reused below)
     // ---- epilogue: output transform per (tile, channel), scale/shift (+res) (+relu), store ----------------------------
     // acc[f][nb][r]: tile 4 kq + r of this wave = (tile row kq>>1, tile column 4 (kq&1) + r), channel ct*64 + nb*16 + (lane&15)
     {
@@ -426,6 +443,7 @@ extern "C" int bevf_conv3x3_wino_f32(const bevf_conv_desc* d, void* stream) {
   BEVF_REQUIRE((long long)d->N * d->H * d->W * d->x_cs * 4 < (1ll << 31) && (long long)d->N * d->H * d->W * d->y_cs * 4 < (1ll << 31) &&
                    (!d->res || (long long)d->N * d->H * d->W * d->res_cs * 4 < (1ll << 31)),
                "conv_wino: activations must stay below 2 GiB (32-bit buffer offsets)");
+  BEVF_REQUIRE((long long)((d->Cout + 63) / 64) * 64 * 16 * d->Cin * 4 < (1ll << 31), "conv_wino: transformed filters must stay below 2 GiB");
   WinoArgs a;
   a.x = d->x; a.u = d->w; a.scale = d->scale; a.shift = d->shift; a.res = d->res; a.y = d->y;
   a.stats = d->stats; a.pivot = d->stats_pivot;
