@@ -128,6 +128,7 @@ SIGNATURES = {
     "bevf_conv2d_nhwc_bf16": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "bevf_stem_pack_bf16": (C.c_int, [C.c_void_p] * 3),
     "bevf_stem_conv7x7_bf16mma": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
+    "bevf_stem_pool_bf16mma": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p]),
     "bevf_stem_conv7x7_bf16out": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_maxpool3x3s2_nhwc_bf16": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_pointwise_smallk_bf16out": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
@@ -340,6 +341,16 @@ def stem_pool(x: torch.Tensor, w_packed: torch.Tensor, scale, shift, y: torch.Te
     if x.numel() != N * 3 * H * W or w_packed.numel() != 148 * 64 or y.numel() < N * Hp * Wp * 64:
         raise BevfError("stem_pool: buffer sizes do not match N,H,W")
     _check(lib().bevf_stem_pool_f32(_pc(x), _pc(w_packed), _pc(scale), _pc(shift), _p(y), N, H, W, _stream()), "bevf_stem_pool_f32")
+
+
+def stem_pool_bf16mma(x: torch.Tensor, w_packed: torch.Tensor, scale, shift, y: torch.Tensor, N: int, H: int, W: int):
+    """bf16 stem + BN + ReLU + 3x3/s2 max-pool in one kernel: (N,3,H,W) fp32 -> pooled bf16 NHWC [N][Hp][Wp][64]."""
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+    if x.numel() != N * 3 * H * W or w_packed.numel() != 64 * 176 or y.numel() < N * Hp * Wp * 64:
+        raise BevfError("stem_pool bf16: buffer sizes do not match N,H,W")
+    _check(lib().bevf_stem_pool_bf16mma(_pc(x), _pc(w_packed, torch.bfloat16), _pc(scale), _pc(shift), _p(y, torch.bfloat16),
+                                        N, H, W, _stream()), "bevf_stem_pool_bf16mma")
 
 
 def maxpool3x3s2(x: torch.Tensor, y: torch.Tensor, N: int, H: int, W: int, Cc: int):

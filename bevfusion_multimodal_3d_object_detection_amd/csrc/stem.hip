@@ -709,6 +709,160 @@ __global__ __launch_bounds__(256) void stem_conv7x7_bf16mma(const float* __restr
 
 constexpr size_t kStemBf16Lds = (size_t)HP * CP + (size_t)3 * PR * PW * 2;
 
+// ---- bf16 stem + 3x3/s2 max-pool in one kernel (bf16-storage inference): the streaming structure of stem_pool7x7 on the
+// bf16 MFMA path above.  A workgroup owns a strip of 120 new stem columns and a segment of pooled rows; per stem row it runs
+// two half rows of 62 pixels (the column tile still has 64 rows; wave (mi, ni) takes pixels 30 mi .. 30 mi + 31 of the
+// half and channels 32 ni ..), so the four 32-pixel wave tiles of a row start 30 pixels apart and every pooling window
+// lies inside one wave's tile; vertical state (the horizontal maxima of the last two stem rows) stays in registers.
+// max commutes with the (monotonic) bf16 rounding and a missing neighbour counts as 0 after the ReLU, so the result is
+// bit-identical to bevf_stem_conv7x7_bf16mma followed by bevf_maxpool3x3s2_nhwc_bf16 -- without the 2.2 GB bf16 stem map.
+__global__ __launch_bounds__(256) void stem_pool7x7_bf16mma(const float* __restrict__ x, const __bf16* __restrict__ w,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             __bf16* __restrict__ y, int H, int W, int Ho, int Wo, int Hp, int Wp,
+                                                             int tilesW, int nseg, int rows_per_seg) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* const col = reinterpret_cast<char*>(smem);                 // [HP][CP]   bf16 column tile
+  char* const wt = col;                                            // [64][CP]   bf16 filter (transient)
+  char* const patch = col + HP * CP;                               // [3][PR][PW] bf16
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tw = blockIdx.x % tilesW;
+  const int seg = (blockIdx.x / tilesW) % nseg;
+  const int n = blockIdx.x / (tilesW * nseg);
+  const int ow0 = tw * TPS - 2;
+  const int p0 = seg * rows_per_seg, p1 = p0 + rows_per_seg < Hp ? p0 + rows_per_seg : Hp;
+  const int r_first = 2 * p0 - 1, r_last = 2 * (p1 - 1) + 1;       // stem rows this segment needs
+  for (int i = tid; i < 64 * (KP / 8); i += 256) {
+    const int ch = i / (KP / 8), q = i - ch * (KP / 8);
+    *reinterpret_cast<u32x4*>(wt + ch * CP + q * 16) = *reinterpret_cast<const u32x4*>(w + (size_t)ch * KP + q * 8);
+  }
+  __syncthreads();
+  const int h = lane >> 5, l31 = lane & 31;
+  const int mi = wave >> 1, ni = wave & 1;
+  const float sc = scale[ni * 32 + l31], sh = shift[ni * 32 + l31];
+  const char* const a_rd = col + (mi * WPX + l31) * CP + h * 16;
+  const char* const b_rd = wt + (ni * 32 + l31) * CP + h * 16;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  constexpr int NG = KP / 16;
+  bf16x8s bfrag[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) bfrag[g] = *reinterpret_cast<const bf16x8s*>(b_rd + g * 32);
+  __syncthreads();                                                 // filter bank consumed: its storage becomes the column tile
+  if (tid < HP) *reinterpret_cast<u32x4*>(col + tid * CP + 168 * 2) = u32x4{0u, 0u, 0u, 0u};
+  const int xp = tid & (HP - 1), xr0 = tid >> 6;
+  const bool vec_ok = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
+  float prev1[2][8], prev2[2][8];                                  // [half][centre]: horizontal maxima of the last two stem rows
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { prev1[a][i] = 0.f; prev2[a][i] = 0.f; }
+
+  for (int oh0 = r_first; oh0 <= r_last; oh0 += TH) {
+    __syncthreads();                                               // the previous chunk's patch is fully consumed
+    {                                                              // patch rows 2*oh0 - 3 .., columns 2*ow0 - 4 .. as bf16
+      const float* img = x + (size_t)n * 3 * H * W;
+      const int iw0 = 2 * ow0 - 4;
+      const int wv = __builtin_amdgcn_readfirstlane(wave);
+      for (int r = wv; r < 3 * PR; r += 4) {
+        const int c = r / PR, pr = r - c * PR;
+        const int ih = 2 * oh0 - 3 + pr;
+        const bool row_ok = (unsigned)ih < (unsigned)H;
+        const float* row = img + ((size_t)c * H + (row_ok ? ih : 0)) * W;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(row), 0, row_ok ? W * 4 : 0, 0x00020000);
+        for (int c4 = lane; c4 < PW / 4; c4 += 64) {
+          const int iw = iw0 + 4 * c4;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (vec_ok) {
+            v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, iw >= 0 ? (unsigned)(iw * 4) : 0x80000000u, 0, 0));
+          } else if (row_ok) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if ((unsigned)(iw + j) < (unsigned)W) v[j] = row[iw + j];
+          }
+          bf16x4s b;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) b[j] = (__bf16)v[j];
+          *reinterpret_cast<bf16x4s*>(patch + ((size_t)r * PW + 4 * c4) * 2) = b;
+        }
+      }
+    }
+    __syncthreads();
+    for (int ro = 0; ro < TH; ++ro) {
+      const int oh = oh0 + ro;
+      if (oh > r_last) break;
+      const bool row_ok = (unsigned)oh < (unsigned)Ho;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        if (ow0 + hf * 2 * WPX >= Wo) break;                       // (uniform) nothing of this half exists
+        {
+          unsigned d[6][4];
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            const int r = xr0 + 4 * j;
+            if (r < 21) {
+              const int c = r / 7, kh = r - c * 7;
+              const unsigned* src = reinterpret_cast<const unsigned*>(patch + ((size_t)(c * PR + 2 * ro + kh) * PW + 2 * (hf * 2 * WPX + xp)) * 2);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) d[j][q] = src[q];
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            const int r = xr0 + 4 * j;
+            if (r < 21) {
+              u32x4 o;
+              o[0] = __builtin_amdgcn_alignbit(d[j][1], d[j][0], 16);
+              o[1] = __builtin_amdgcn_alignbit(d[j][2], d[j][1], 16);
+              o[2] = __builtin_amdgcn_alignbit(d[j][3], d[j][2], 16);
+              o[3] = d[j][3] >> 16;
+              *reinterpret_cast<u32x4*>(col + xp * CP + r * 16) = o;
+            }
+          }
+        }
+        __syncthreads();
+        bf16x8s afrag[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) afrag[g] = *reinterpret_cast<const bf16x8s*>(a_rd + g * 32);
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[g], bfrag[g], g == 0 ? zero : acc, 0, 0, 0);
+        // BatchNorm + ReLU as the unfused kernel stores them (before its bf16 rounding); missing rows / columns count as 0
+        const int col0 = ow0 + hf * 2 * WPX + mi * WPX + 4 * h;    // stem column of register 0 of this lane
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool ok = row_ok && (unsigned)(col0 + (r & 3) + 8 * (r >> 2)) < (unsigned)Wo;
+          v[r] = ok ? fmaxf(fmaf(acc[r], sc, sh), 0.f) : 0.f;
+        }
+        float hm[8], xl[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xl[g] = __shfl_xor(v[4 * g + 3], 32);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float l0 = h ? xl[g] : (g > 0 ? xl[g - 1] : 0.f);
+          hm[2 * g] = fmaxf(fmaxf(l0, v[4 * g]), v[4 * g + 1]);
+          hm[2 * g + 1] = fmaxf(fmaxf(v[4 * g + 1], v[4 * g + 2]), v[4 * g + 3]);
+        }
+        if (oh & 1) {                                              // stem row 2p+1 completes pooled row p (uniform branch)
+          const int pr = (oh - 1) >> 1;
+          if (pr >= p0 && pr < p1) {
+            __bf16* const yrow = y + ((size_t)(n * Hp + pr) * Wp) * 64 + ni * 32 + l31;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+              const int rc = 2 * c;
+              const int cc = col0 + (rc & 3) + 8 * (rc >> 2);      // stem column of the window centre (even)
+              const bool own = (h != 0 || c != 0) && cc >= 0 && (cc >> 1) < Wp;
+              if (own) yrow[(size_t)(cc >> 1) * 64] = (__bf16)fmaxf(fmaxf(prev2[hf][c], prev1[hf][c]), hm[c]);
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { prev2[hf][i] = prev1[hf][i]; prev1[hf][i] = hm[i]; }
+        __syncthreads();                                           // column tile free for the next expansion
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void stem_pack_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= 64 * KP) return;
@@ -747,4 +901,37 @@ extern "C" int bevf_stem_conv7x7_bf16mma(const float* x, const void* w_packed, c
                      static_cast<hipStream_t>(stream), x, static_cast<const __bf16*>(w_packed), scale, shift,
                      static_cast<__bf16*>(y), H, W, Ho, Wo, tilesW, tilesH, relu);
   return bevf_check_launch("bevf_stem_conv7x7_bf16mma");
+}
+
+// bf16 stem + max-pool fused (fp32 image in, bf16 pooled NHWC out [N][Hp][Wp][64]); bit-identical to
+// bevf_stem_conv7x7_bf16mma (relu) followed by bevf_maxpool3x3s2_nhwc_bf16
+extern "C" int bevf_stem_pool_bf16mma(const float* x, const void* w_packed, const float* scale, const float* shift, void* y, int N,
+                                      int H, int W, void* stream) {
+  BEVF_REQUIRE(x && w_packed && scale && shift && y, "stem_pool bf16: null pointer");
+  BEVF_REQUIRE(bevf_aligned16(w_packed), "stem_pool bf16: packed filter bank must be 16-byte aligned");
+  BEVF_REQUIRE(N > 0 && H >= 1 && W >= 1, "stem_pool bf16: empty shape");
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+  const int Hp = (Ho + 2 - 3) / 2 + 1, Wp = (Wo + 2 - 3) / 2 + 1;
+  const int tilesW = (Wp + TPS / 2 - 1) / (TPS / 2);
+  // segments of pooled rows: fewest (rounds of 768 resident workgroups: 44 KB of LDS each) x (chunks of 4 stem rows per workgroup)
+  int best_seg = 1;
+  long long best_cost = -1;
+  for (int ns = 1; ns <= 32 && ns <= Hp; ++ns) {
+    const int rps = (Hp + ns - 1) / ns, real = (Hp + rps - 1) / rps;
+    const long long wgs = (long long)N * tilesW * real;
+    const long long cost = ((wgs + 767) / 768) * ((2 * rps + 1 + TH - 1) / TH);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_seg = real; }
+  }
+  const int rps = (Hp + best_seg - 1) / best_seg, nseg = (Hp + rps - 1) / rps;
+  const long long grid = (long long)N * tilesW * nseg;
+  BEVF_REQUIRE(grid < (1ll << 31), "stem_pool bf16: grid too large");
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool7x7_bf16mma), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)kStemBf16Lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(stem_pool7x7_bf16mma, dim3((unsigned)grid), dim3(256), kStemBf16Lds, static_cast<hipStream_t>(stream), x,
+                     static_cast<const __bf16*>(w_packed), scale, shift, static_cast<__bf16*>(y), H, W, Ho, Wo, Hp, Wp, tilesW, nseg, rps);
+  return bevf_check_launch("bevf_stem_pool_bf16mma");
 }

@@ -222,7 +222,7 @@ def _conv_call(pc: PackedConv, x, y, N, H, W, x_cs=None, y_cs=None, res=None, co
 
 # ---- camera encoder (ref src/encoders.py:133-172) -----------------------------------------------------
 
-FUSE_STEM_POOL = True        # fp32 inference: stem + max-pool as one kernel (csrc/stem.hip: stem_pool7x7)
+FUSE_STEM_POOL = True        # inference: stem + max-pool as one kernel (csrc/stem.hip: stem_pool7x7, stem_pool7x7_bf16mma)
 
 
 class CameraEncoderEngine(_Engine):
@@ -271,11 +271,14 @@ class CameraEncoderEngine(_Engine):
         H1, W1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         H2, W2 = (H1 - 1) // 2 + 1, (W1 - 1) // 2 + 1
         cur = self.buf("act0", N * H2 * W2 * 64)
-        if self.stem_w_bf16 is None and FUSE_STEM_POOL:
-            # fp32: conv1 + bn1 + relu + maxpool in ONE kernel -- the stem map (4.4 GB at 48 images of 900x1600, the largest
-            # activation of the path) never reaches HBM; bit-identical to the two kernels below
+        if FUSE_STEM_POOL:
+            # conv1 + bn1 + relu + maxpool in ONE kernel -- the stem map (4.4 GB fp32 / 2.2 GB bf16 at 48 images of 900x1600, the
+            # largest activation of the path) never reaches HBM; bit-identical to the two kernels below
             with _span("stem_conv7x7_f32", flops=2.0 * N * H1 * W1 * 64 * 147):
-                L.stem_pool(x, self.stem_w, self.stem_scale, self.stem_shift, cur, N, H, W)
+                if self.stem_w_bf16 is not None:
+                    L.stem_pool_bf16mma(x.float(), self.stem_w_bf16, self.stem_scale, self.stem_shift, cur, N, H, W)
+                else:
+                    L.stem_pool(x, self.stem_w, self.stem_scale, self.stem_shift, cur, N, H, W)
         else:
             stem = self.buf("stem", N * H1 * W1 * 64)
             with _span("stem_conv7x7_f32", flops=2.0 * N * H1 * W1 * 64 * 147):

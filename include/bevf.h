@@ -314,7 +314,12 @@ int bevf_stem_conv7x7_bf16out(const float* x, const float* w, const float* scale
  * accumulate, folded BN + ReLU, bf16 NHWC out.                                                                   */
 int bevf_stem_pack_bf16(const float* w_oihw, void* packed, void* stream);
 int bevf_stem_conv7x7_bf16mma(const float* x, const void* w_packed, const float* scale, const float* shift, void* y,
-                              int N, int H, int W, int relu, void* stream);     /* fp32 image + fp32 MFMA, bf16 NHWC out */
+                              int N, int H, int W, int relu, void* stream); /* The bf16 stem and the 3x3/s2 max-pool in one kernel (bf16-storage inference): fp32 image in, pooled bf16 NHWC
+ * [N][Hp][Wp][64] out, bit-identical to bevf_stem_conv7x7_bf16mma (relu = 1) followed by bevf_maxpool3x3s2_nhwc_bf16;
+ * the 64-channel stem map never reaches HBM (ref src/encoders.py:154-157).                                          */
+int bevf_stem_pool_bf16mma(const float* x, const void* w_packed, const float* scale, const float* shift, void* y, int N,
+                           int H, int W, void* stream);
+    /* fp32 image + fp32 MFMA, bf16 NHWC out */
 int bevf_maxpool3x3s2_nhwc_bf16(const void* x, void* y, int N, int H, int W, int C, void* stream);
 int bevf_pointwise_smallk_bf16out(const float* x, const float* w, const float* scale, const float* shift, void* y,
                                   int M, int K, int Cout, int relu, void* stream);
