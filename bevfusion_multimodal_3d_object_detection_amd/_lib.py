@@ -269,8 +269,10 @@ def wino_filter_transform(w_ohwi: torch.Tensor, Cout: int, Cin: int) -> torch.Te
 
 def conv3x3_wino(x: torch.Tensor, u: torch.Tensor, scale, shift, y: torch.Tensor, *, N: int, H: int, W: int, Cin: int,
                  x_cs: int, Cout: int, y_cs: int, relu: bool, res: Optional[torch.Tensor] = None, res_cs: int = 0,
-                 stats: Optional[torch.Tensor] = None, stats_pivot: Optional[torch.Tensor] = None, bnb: Optional[dict] = None) -> None:
+                 stats: Optional[torch.Tensor] = None, stats_pivot: Optional[torch.Tensor] = None, bnb: Optional[dict] = None,
+                 tile: int = 0) -> None:
     """3x3 / stride 1 / pad 1 convolution as fused fp32 Winograd F(2x2,3x3); `u` from wino_filter_transform.
+    tile: 0 = the block geometry that covers the map with fewer blocks, 1 = 16x16-pixel blocks, 2 = 32x8-pixel blocks.
     `stats` [bevf_wino_stat_rows(N,H,W)][Cout][2]: also leave the BatchNorm partial sums of the output (training)."""
     if stats is not None and stats.numel() < lib().bevf_wino_stat_rows(N, H, W) * Cout * 2:
         raise BevfError("conv_wino: stats buffer too small")
@@ -289,7 +291,7 @@ def conv3x3_wino(x: torch.Tensor, u: torch.Tensor, scale, shift, y: torch.Tensor
         if v is not None and v.numel() != Cout:
             raise BevfError("conv_wino: scale/shift length != Cout")
     d = ConvDesc(_p(x), _pc(u), _pc(scale), _pc(shift), _p(res), _p(y), None, N, H, W, Cin, x_cs, H, W, Cout, y_cs, res_cs,
-                 3, 3, 1, 1, int(relu), 0, 0, _p(stats), _pc(stats_pivot))
+                 3, 3, 1, 1, int(relu), 0, int(tile), _p(stats), _pc(stats_pivot))
     if bnb is not None:       # this conv's output is dY of a train-mode BatchNorm(+ReLU) layer: mask + backward sums in the epilogue
         for k in ("x", "mean", "invstd"):
             if bnb.get(k) is None:

@@ -52,14 +52,19 @@ struct WinoArgs {
 };
 
 constexpr int PIX = 18 * 18, PITCH = 36;                       // patch pixels, floats per pixel in LDS (32 + 4 pad)
-constexpr int PSLOTS = PIX * 9;                                // 16-byte slots of a patch chunk: 8 data + 1 pad per pixel
 constexpr int PDMA = 12;                                       // LDS-DMA instructions per wave and chunk (4 waves x 12 x 64 slots)
-constexpr int PATCH_FLOATS = 4 * PDMA * 64 * 4;                // 12288 floats = 48 KiB: the 2916 slots rounded up to 48 x 64
+constexpr int PATCH_FLOATS = 4 * PDMA * 64 * 4;                // 12288 floats = 48 KiB: 9 16-byte slots per pixel (8 data + 1 pad), 2916 / 3060 slots rounded up to 48 x 64
 constexpr int BG_FLOATS = 16 * 4 * 16 * 8;                     // 8192 floats = 32 KB per channel group
 constexpr int LDS_BYTES = (2 * PATCH_FLOATS + 2 * BG_FLOATS) * 4;
 
-template <bool RES, bool RELU, bool STATS = false, int BNB = 0>
+// GEO = block geometry: 0 = 8x8 tiles (16x16 pixels; wave w: tile rows 2w, 2w+1), 1 = 16x4 tiles (32 rows x 8 columns; wave w:
+// tile rows 4w .. 4w+3) -- the host takes whichever covers the map with fewer blocks (57x100: 28 -> 26, 113x200: 104 -> 100).
+template <bool RES, bool RELU, bool STATS = false, int BNB = 0, int GEO = 0>
 __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
+  constexpr int BHP = GEO ? 32 : 16, BWP = GEO ? 8 : 16;          // block height / width in pixels
+  constexpr int PWP = BWP + 2, PIXG = (BHP + 2) * PWP;            // patch width, patch pixels (324 or 340)
+  constexpr int PSLOTSG = PIXG * 9;
+  static_assert(PSLOTSG <= 4 * PDMA * 64, "patch does not fit the DMA image");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const patch = lds;                                     // [2][PIX][PITCH]
   float* const bbuf = lds + 2 * PATCH_FLOATS;                   // [2][BG_FLOATS]
@@ -80,15 +85,15 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
     sp /= p.TBX;
     by = sp % p.TBY;
     n = sp / p.TBY;
-    const int iy0 = 16 * by - 1, ix0 = 16 * bx - 1;
+    const int iy0 = BHP * by - 1, ix0 = BWP * bx - 1;
     const bool live = tile < ntiles;
 #pragma unroll
     for (int j = 0; j < PDMA; ++j) {
       const int sl = (4 * j + wave) * 64 + lane;
       const int pix = (sl * 7282) >> 16, piece = sl - 9 * pix;                                  // sl / 9 for sl < 3072
-      const int py = (pix * 3641) >> 16, px = pix - py * 18;                                    // pix / 18 for pix < 1024
+      const int py = (pix * (GEO ? 6554 : 3641)) >> 16, px = pix - py * PWP;                    // pix / 18 (or / 10) for pix < 1024
       const int iy = iy0 + py, ix = ix0 + px;
-      const bool ok = live && sl < PSLOTS && piece < 8 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const bool ok = live && sl < PSLOTSG && piece < 8 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
       pv[j] = ok ? (unsigned)((((n * p.H + iy) * p.W + ix) * p.x_cs + 4 * piece) * 4) : kOob;
     }
   };
@@ -109,8 +114,8 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
 
   // ---- compute roles --------------------------------------------------------------------------------------------
   const int t = lane & 15, kq = lane >> 4;
-  const int ty = 2 * wave + (t >> 3), tx = t & 7;
-  const int a_lane = ((2 * ty) * 18 + 2 * tx) * PITCH + 2 * kq;    // floats: patch pixel (2ty, 2tx), channels 2kq..
+  const int ty = GEO ? 4 * wave + (t >> 2) : 2 * wave + (t >> 3), tx = GEO ? (t & 3) : (t & 7);
+  const int a_lane = ((2 * ty) * PWP + 2 * tx) * PITCH + 2 * kq;    // floats: patch pixel (2ty, 2tx), channels 2kq..
   const int b_lane = ((kq >> 1) * 16 + t) * 8 + (kq & 1) * 4;      // floats within a [2 kh][16 n][2][2 nb][2 cin] block
 
   f32x4 acc[16][4];
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
   auto load_patch = [&](int buf, int gl, int q) {                  // row q of the 4x4 patch -> dn[4q..4q+3]
     const float* pa = patch + buf * PATCH_FLOATS + a_lane + gl * 8;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) dn[4 * q + c] = *reinterpret_cast<const f32x2*>(pa + (q * 18 + c) * PITCH);
+    for (int c = 0; c < 4; ++c) dn[4 * q + c] = *reinterpret_cast<const f32x2*>(pa + (q * PWP + c) * PITCH);
   };
   auto rows_col = [&](int c) {                                      // B^T d, column c (in place)
     const f32x2 t0 = dn[0 + c] - dn[8 + c], t1 = dn[4 + c] + dn[8 + c], t2 = dn[8 + c] - dn[4 + c], t3 = dn[4 + c] - dn[12 + c];
@@ -189,10 +194,10 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
         if (k == 0 && f < 15) bn[0] = *reinterpret_cast<const f32x4*>(pb + ((f + 1) * 2) * 256);
         if (k == 1 && f < 15) bn[1] = *reinterpret_cast<const f32x4*>(pb + ((f + 1) * 2 + 1) * 256);
         if (f < 4) {                                                // patch row f of the next group: 4 x b64
-          if (k == 2) { dn[4 * f + 0] = *reinterpret_cast<const f32x2*>(pa + (f * 18 + 0) * PITCH);
-                        dn[4 * f + 1] = *reinterpret_cast<const f32x2*>(pa + (f * 18 + 1) * PITCH); }
-          if (k == 3) { dn[4 * f + 2] = *reinterpret_cast<const f32x2*>(pa + (f * 18 + 2) * PITCH);
-                        dn[4 * f + 3] = *reinterpret_cast<const f32x2*>(pa + (f * 18 + 3) * PITCH); }
+          if (k == 2) { dn[4 * f + 0] = *reinterpret_cast<const f32x2*>(pa + (f * PWP + 0) * PITCH);
+                        dn[4 * f + 1] = *reinterpret_cast<const f32x2*>(pa + (f * PWP + 1) * PITCH); }
+          if (k == 3) { dn[4 * f + 2] = *reinterpret_cast<const f32x2*>(pa + (f * PWP + 2) * PITCH);
+                        dn[4 * f + 3] = *reinterpret_cast<const f32x2*>(pa + (f * PWP + 3) * PITCH); }
         } else if (f < 8) {                                         // B^T d, column c = f - 4: four f32x2 ops
           const int c = f - 4;
           if (k == 2) { const f32x2 t0 = dn[0 + c] - dn[8 + c], t1 = dn[4 + c] + dn[8 + c];
@@ -250,8 +255,9 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
     // ---- epilogue: output transform per (tile, channel), scale/shift (+res) (+relu), store ----------------------------
     // acc[f][nb][r]: tile 4 kq + r of this wave = (tile row kq>>1, tile column 4 (kq&1) + r), channel ct*64 + nb*16 + (lane&15)
     {
-      const int oy = 16 * by + 4 * wave + 2 * (kq >> 1), ox = 16 * bx + 8 * (kq & 1);
-      const bool interior = 16 * by + 16 <= p.H && 16 * bx + 16 <= p.W && ct * 64 + 64 <= p.Cout;
+      // (GEO 1: tile 4 kq + r = tile row kq of the wave's four, tile column r)
+      const int oy = GEO ? 32 * by + 8 * wave + 2 * kq : 16 * by + 4 * wave + 2 * (kq >> 1), ox = GEO ? 8 * bx : 16 * bx + 8 * (kq & 1);
+      const bool interior = BHP * by + BHP <= p.H && BWP * bx + BWP <= p.W && ct * 64 + 64 <= p.Cout;
       const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)kOob, 0x00020000);
       const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res), 0, (int)kOob, 0x00020000);
       const unsigned y_lane = (unsigned)((((n * p.H + oy) * p.W + ox) * p.y_cs + ct * 64 + t) * 4);
@@ -457,6 +463,10 @@ extern "C" int bevf_conv3x3_wino_f32(const bevf_conv_desc* d, void* stream) {
   }
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.x_cs = d->x_cs; a.Cout = d->Cout; a.y_cs = d->y_cs; a.res_cs = d->res_cs;
   a.TBY = (d->H + 15) / 16; a.TBX = (d->W + 15) / 16; a.nct = (d->Cout + 63) / 64;
+  // block geometry: 32x8-pixel blocks where they cover the map with fewer blocks (plain epilogues only: the statistics rows are per 16x16 block)
+  const long long b16 = (long long)a.TBY * a.TBX, b32 = (long long)((d->H + 31) / 32) * ((d->W + 7) / 8);
+  const bool geo1 = !d->stats && !d->bnb_x && d->tile != 1 && (b32 < b16 || d->tile == 2);
+  if (geo1) { a.TBY = (d->H + 31) / 32; a.TBX = (d->W + 7) / 8; }
   const long long ntiles = (long long)d->N * a.TBY * a.TBX * a.nct;
   BEVF_REQUIRE(ntiles < (1ll << 31), "conv_wino: too many tiles");
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -490,6 +500,24 @@ extern "C" int bevf_conv3x3_wino_f32(const bevf_conv_desc* d, void* stream) {
   }
   if (d->stats) {
     hipLaunchKernelGGL((wino_f32<false, false, true>), grid, block, LDS_BYTES, st, a);
+    return bevf_check_launch("bevf_conv3x3_wino_f32");
+  }
+  if (geo1) {
+    static bool attr1 = false;
+    if (!attr1) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_f32<false, false, false, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_f32<false, true, false, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_f32<true, false, false, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_f32<true, true, false, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      attr1 = true;
+    }
+    if (d->res) {
+      if (d->relu) hipLaunchKernelGGL((wino_f32<true, true, false, 0, 1>), grid, block, LDS_BYTES, st, a);
+      else hipLaunchKernelGGL((wino_f32<true, false, false, 0, 1>), grid, block, LDS_BYTES, st, a);
+    } else {
+      if (d->relu) hipLaunchKernelGGL((wino_f32<false, true, false, 0, 1>), grid, block, LDS_BYTES, st, a);
+      else hipLaunchKernelGGL((wino_f32<false, false, false, 0, 1>), grid, block, LDS_BYTES, st, a);
+    }
     return bevf_check_launch("bevf_conv3x3_wino_f32");
   }
   if (d->res) {

@@ -68,12 +68,17 @@ def test_conv_wino_against_fp64_and_direct(gpu, N, H, W, cin, cout, res, relu, x
     rb = _nhwc(rs).view(-1).cuda() if res else None
     w_ohwi = _nhwc(w).view(-1).cuda()
     u = L.wino_filter_transform(w_ohwi, cout, cin)
-    y = torch.full((M * ycs,), -5.0, device=gpu)
-    L.conv3x3_wino(xb.view(-1).cuda(), u, scale.cuda(), shift.cuda(), y, N=N, H=H, W=W, Cin=cin, x_cs=xcs, Cout=cout, y_cs=ycs,
-                   relu=relu, res=rb, res_cs=cout if res else 0)
-    got = y.view(M, ycs).cpu()
-    assert rel_err(got[:, :cout].view(N, H, W, cout).permute(0, 3, 1, 2), ref) <= 2e-6
-    assert bool((got[:, cout:] == -5.0).all())                              # nothing written past Cout in a wider pixel
+    outs = []
+    for tile in (0, 1, 2):                                                  # auto, 16x16-pixel blocks, 32x8-pixel blocks
+        y = torch.full((M * ycs,), -5.0, device=gpu)
+        L.conv3x3_wino(xb.view(-1).cuda(), u, scale.cuda(), shift.cuda(), y, N=N, H=H, W=W, Cin=cin, x_cs=xcs, Cout=cout, y_cs=ycs,
+                       relu=relu, res=rb, res_cs=cout if res else 0, tile=tile)
+        got = y.view(M, ycs).cpu()
+        assert rel_err(got[:, :cout].view(N, H, W, cout).permute(0, 3, 1, 2), ref) <= 2e-6
+        assert bool((got[:, cout:] == -5.0).all())                          # nothing written past Cout in a wider pixel
+        outs.append(got)
+    # the geometry changes which block a tile belongs to, not the tile's arithmetic: bit-identical results
+    assert torch.equal(outs[1], outs[2]) and torch.equal(outs[0], outs[1])
     yd = torch.zeros(M * ycs, device=gpu)
     L.conv2d_nhwc(xb.view(-1).cuda(), w_ohwi, scale.cuda(), shift.cuda(), yd, N=N, H=H, W=W, Cin=cin, x_cs=xcs, Cout=cout, y_cs=ycs,
                   KH=3, KW=3, stride=1, pad=1, relu=relu, res=rb, res_cs=cout if res else 0)

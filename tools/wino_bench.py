@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Fused fp32 Winograd convolution on the 3x3 / stride 1 layer shapes of config 2 at B=8 (TF direct-equivalent)."""
+"""Fused fp32 Winograd convolution on the 3x3 / stride 1 layer shapes of config 2 at B=8 (TF direct-equivalent), with both
+block geometries (16x16-pixel and 32x8-pixel blocks; the launcher picks the one with fewer blocks)."""
 import os
 import sys
 
@@ -13,6 +14,7 @@ SHAPES = {  # name: (N, H, W, Cin, Cout, residual)
     "layer2": (48, 113, 200, 128, 128, True), "layer3": (48, 57, 100, 256, 256, True),
     "fusion1": (8, 128, 128, 512, 512, False), "fusion2": (8, 128, 128, 512, 256, False), "head": (8, 128, 128, 256, 320, False),
     "lift": (8, 128, 128, 64, 128, False), "odd": (3, 37, 45, 96, 80, True),
+    "t_layer2": (48, 56, 100, 128, 128, True), "t_layer3": (48, 28, 50, 256, 256, True), "t_layer4": (48, 14, 25, 512, 512, True),
 }
 dev = torch.device("cuda")
 names = sys.argv[1].split(",") if len(sys.argv) > 1 else list(SHAPES)
@@ -24,17 +26,20 @@ for name in names:
     sc, sh = torch.rand(Cout, device=dev) + 0.5, torch.randn(Cout, device=dev)
     r = torch.randn(N * H * W * Cout, device=dev) if res else None
     flops = 2.0 * N * H * W * Cout * 9 * Cin
-    y = torch.empty(N * H * W * Cout, device=dev)
-    run = lambda: L.conv3x3_wino(x, u, sc, sh, y, N=N, H=H, W=W, Cin=Cin, x_cs=Cin, Cout=Cout, y_cs=Cout, relu=True,
-                                 res=r, res_cs=Cout if res else 0)
-    for _ in range(3):
-        run()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 10
-    print(f"{name:8s} N={N} {H}x{W} {Cin}->{Cout}{' +res' if res else ''}: {ms * 1e3:8.1f} us {flops / ms / 1e9:6.1f} TF", flush=True)
+    line = f"{name:8s} N={N} {H}x{W} {Cin}->{Cout}{' +res' if res else ''}:"
+    for tile, label in ((1, "16x16 blocks"), (2, "32x8 blocks")):
+        y = torch.empty(N * H * W * Cout, device=dev)
+        run = lambda: L.conv3x3_wino(x, u, sc, sh, y, N=N, H=H, W=W, Cin=Cin, x_cs=Cin, Cout=Cout, y_cs=Cout, relu=True,
+                                     res=r, res_cs=Cout if res else 0, tile=tile)
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        line += f"  {label} {ms * 1e3:8.1f} us {flops / ms / 1e9:6.1f} TF"
+    print(line, flush=True)
