@@ -35,7 +35,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct WinoArgs {
   const float* x;      // NHWC, channel stride x_cs
-  const float* u;      // [ct][G][16 f][2 nb pair][2 kh][16 n][2][2 nb][2 cin]: bevf_wino_filter_transform_f32
+  const float* u;      // [ct][G][16 f][2 nb pair][4 kq][16 n][2 nb][2 cin]: bevf_wino_filter_transform_f32
   const float* scale;  // [Cout] or null
   const float* shift;
   const float* res;    // NHWC residual or null
@@ -51,7 +51,7 @@ struct WinoArgs {
   int TBY, TBX, nct;   // tile blocks per image (rows, cols), 64-channel slabs
 };
 
-constexpr int PIX = 18 * 18, PITCH = 36;                       // patch pixels, floats per pixel in LDS (32 + 4 pad)
+constexpr int PITCH = 36;                                      // floats per patch pixel in LDS (32 + 4 pad); 18x18 or 34x10 pixels
 constexpr int PDMA = 12;                                       // LDS-DMA instructions per wave and chunk (4 waves x 12 x 64 slots)
 constexpr int PATCH_FLOATS = 4 * PDMA * 64 * 4;                // 12288 floats = 48 KiB: 9 16-byte slots per pixel (8 data + 1 pad), 2916 / 3060 slots rounded up to 48 x 64
 constexpr int BG_FLOATS = 16 * 4 * 16 * 8;                     // 8192 floats = 32 KB per channel group
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
   constexpr int PSLOTSG = PIXG * 9;
   static_assert(PSLOTSG <= 4 * PDMA * 64, "patch does not fit the DMA image");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* const patch = lds;                                     // [2][PIX][PITCH]
+  float* const patch = lds;                                     // [2][patch pixels][PITCH] (padded to PATCH_FLOATS)
   float* const bbuf = lds + 2 * PATCH_FLOATS;                   // [2][BG_FLOATS]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
   const int t = lane & 15, kq = lane >> 4;
   const int ty = GEO ? 4 * wave + (t >> 2) : 2 * wave + (t >> 3), tx = GEO ? (t & 3) : (t & 7);
   const int a_lane = ((2 * ty) * PWP + 2 * tx) * PITCH + 2 * kq;    // floats: patch pixel (2ty, 2tx), channels 2kq..
-  const int b_lane = ((kq >> 1) * 16 + t) * 8 + (kq & 1) * 4;      // floats within a [2 kh][16 n][2][2 nb][2 cin] block
+  const int b_lane = kq * 64 + t * 4;                              // floats within a [4 kq][16 n][2 nb][2 cin] block: lane * 16 bytes, linear
 
   f32x4 acc[16][4];
   f32x2 v[16], dn[16];
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
 }
 
 
-// OHWI filters [Cout][3][3][Cin] -> U image [ct][G][16 f][2 np][2 kh][16 n][2][2 nbl][2 cin]; U = G g G^T in double
+// OHWI filters [Cout][3][3][Cin] -> U image [ct][G][16 f][2 np][4 kq][16 n][2 nbl][2 cin]; U = G g G^T in double
 __global__ __launch_bounds__(256) void wino_filter_transform(const float* __restrict__ w, float* __restrict__ u, int Cout,
                                                              int Cin, int nct) {
   const long long idx = blockIdx.x * 256ll + threadIdx.x;
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void wino_filter_transform(const float* __rest
   const int G = Cin >> 3, ct = co >> 6, nb = (co & 63) >> 4, nn = co & 15, g8 = ci >> 3, q = ci & 7;
 #pragma unroll
   for (int f = 0; f < 16; ++f)
-    u[((((size_t)ct * G + g8) * 16 + f) * 2 + (nb >> 1)) * 256 + ((q >> 2) * 16 + nn) * 8 + ((q >> 1) & 1) * 4 + (nb & 1) * 2 + (q & 1)] =
+    u[((((size_t)ct * G + g8) * 16 + f) * 2 + (nb >> 1)) * 256 + ((q >> 1) * 16 + nn) * 4 + (nb & 1) * 2 + (q & 1)] =
         (float)U[f >> 2][f & 3];
 }
 

@@ -36,15 +36,15 @@ def test_filter_transform_matches_float64_host(gpu):
     U = torch.einsum("ia,ocab,jb->ocij", G, w.double(), G).float()                  # (cout, cin, 4, 4)
     nct, g8 = (cout + 63) // 64, cin // 8
     assert u.numel() == nct * 64 * 16 * cin
-    img = u.view(nct, g8, 16, 2, 2, 16, 2, 2, 2)             # [ct][g][f][np][kh][n][kq&1][nb&1][cin&1]
+    img = u.view(nct, g8, 16, 2, 4, 16, 2, 2)                # [ct][g][f][np][kq = (cin & 7) >> 1][n][nb&1][cin&1]
     rng = np.random.RandomState(0)
     for _ in range(300):
         co, ci, f = int(rng.randint(cout)), int(rng.randint(cin)), int(rng.randint(16))
         nb, q = (co % 64) // 16, ci % 8
-        got = img[co // 64, ci // 8, f, nb >> 1, q >> 2, co % 16, (q >> 1) & 1, nb & 1, q & 1]
+        got = img[co // 64, ci // 8, f, nb >> 1, q >> 1, co % 16, nb & 1, q & 1]
         assert float(got) == float(U[co, ci, f >> 2, f & 3]), (co, ci, f)
     # output channels 80..127 of the second 64-channel slab (nb = 2 np + nbl >= 1) do not exist: zero rows
-    assert float(img[1, :, :, 1].abs().max()) == 0.0 and float(img[1, :, :, 0, :, :, :, 1].abs().max()) == 0.0
+    assert float(img[1, :, :, 1].abs().max()) == 0.0 and float(img[1, :, :, 0, :, :, 1].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("N,H,W,cin,cout,res,relu,xcs,ycs", [
