@@ -220,7 +220,10 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
     // group end: the filter image (and, after group 2, the whole next patch chunk) has landed; the patch part issued in
     // this group stays in flight.  Wait and barrier are ONE asm with a memory clobber (no LDS access moves across it):
     // through __syncthreads() or a workgroup fence hipcc waits vmcnt(0) here, the DMA being an LDS write to it.
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(gl == 2 ? 0 : 4) : "memory");
+    // (a chunk's last group also lets its MFMAs land: they are inline asm, unseen by hipcc's hazard pass, and hipcc puts accumulator
+    //  copies / the epilogue's v_accvgpr_read right behind the loop)
+    if constexpr (gl == 3) asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(gl == 2 ? 0 : 4) : "memory");
   };
   using G0 = std::integral_constant<int, 0>;
   using G1 = std::integral_constant<int, 1>;

@@ -272,8 +272,10 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_f32(const WwArgs p) {
   for (int s = s_begin; s < s_end; s += 2) {          // steps run in pairs (steps_per_split is even; past the last tile the table
     step(ic<0>{}, s);                                 // holds only out-of-range offsets: a dead step adds zeros)
     step(ic<1>{}, s + 1);
+    // the last MFMAs land before anything behind the loop reads an accumulator (hipcc cannot see the inline-asm MFMAs' latency
+    // and may place accumulator copies directly behind the loop: the wait has to sit inside it)
+    if (s + 2 >= s_end) asm volatile("s_nop 15\n\ts_nop 15");
   }
-  asm volatile("s_nop 15\n\ts_nop 15");               // last MFMA results land before the accumulators are read
 
   // ---- partial block: acc[fc][cb][ib][r] is dU[f = 4 fr + fc][co = co0 + 4 (4k + r) + cb][ci = ci0 + 4q + ib] ------
   float* const pb = p.part + ((size_t)split * 16 + fr * 4) * p.Cout * p.Cin + (size_t)(co0 + 16 * k) * p.Cin + ci0 + 4 * q;
