@@ -68,10 +68,11 @@ def parse_args(argv=None):
                     help="fp32 (default): exact fp32 MFMA.  bf16 = BASELINE configs 3/5: bf16 storage, fp32 accumulate.  "
                          "f32x3: fp32 storage, convolutions through an exact 3-way bf16 split on the bf16 MFMA "
                          "(fp32-level error, not bit-identical to fp32; opt-in, never the headline)")
-    ap.add_argument("--conv", choices=["wino", "f32"], default=DEFAULT_CONV,
+    ap.add_argument("--conv", choices=["wino", "f32", "wino_x3"], default=DEFAULT_CONV,
                     help="fp32 convolution kernels: f32 = exact implicit GEMM (v_mfma_f32_32x32x2_f32) everywhere; wino = fused fp32 "
                          "Winograd F(2x2,3x3) for the 3x3 / stride 1 layers (fp32 products and accumulation, 2.25x fewer MFMA FLOPs, "
-                         "a few 1e-7 relative from the exact kernel), exact implicit GEMM for the rest")
+                         "a few 1e-7 relative from the exact kernel), exact implicit GEMM for the rest; wino_x3 = opt-in: Winograd as "
+                         "above and every other layer through the exact three-plane bf16 split of --dtype f32x3 (fp32-level error)")
     ap.add_argument("--graph", action="store_true", help="replay the inference forward as one hipGraph (small batches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true", help="skip the per-launch HIP-event brackets")
@@ -423,20 +424,26 @@ def main():
     plan = []
     if args.extras != "none" and not args.graph:
         plan = [(3, "bf16", "infer", 8), (5, "bf16", "infer", 2), (4, "fp32", "train", 8)]
+        if args.conv == "wino" and args.dtype == "fp32" and args.mode == "infer" and args.config == 2 and world == 1:
+            # the headline's workload once more with the opt-in mixed convolution mode (NOT the headline: its non-Winograd layers
+            # multiply through three bf16 planes instead of fp32 FMAs; fp32-level error)
+            plan.insert(0, (2, "fp32", "infer", args.batch or 8, "wino_x3"))
         if world > 1 and args.extras == "auto":
             plan = [(4, "fp32", "train", 8)]
-        plan = [p for p in plan if (p[0], p[1], p[2]) != (args.config, args.dtype, args.mode)]
+        plan = [p for p in plan if len(p) > 4 or (p[0], p[1], p[2]) != (args.config, args.dtype, args.mode)]
     # N > 1: the ONE JSON line (the replica headline the scaling curve is computed from) leaves BEFORE the extra leg, whose
     # gradient all-reduce is the only collective of this program: if RCCL misbehaves there, the headline is already out.  The
     # leg's record then goes to stderr (`[bench extra] {...}`).  N = 1: no collective anywhere, one line at the end with everything.
     if world > 1:
         emit([])
     extras = []
-    for config, dtype, mode, batch in plan:
+    for config, dtype, mode, batch, *conv_override in plan:
         if mode == "train":
             ctx["inputs"].drop()
         try:
-            rec, _ = run_leg(config, dtype, mode, batch, args.extra_steps, 2, ctx, conv=args.conv)
+            rec, _ = run_leg(config, dtype, mode, batch, args.extra_steps, 2, ctx, conv=conv_override[0] if conv_override else args.conv)
+            if conv_override:
+                rec["conv_kernels"] = conv_override[0]
         except Exception as e:                               # a failed extra never takes the headline with it
             rec = {"workload": CONFIGS[config]["name"], "dtype": dtype, "error": f"{type(e).__name__}: {e}"[:300]}
         extras.append(rec)

@@ -238,7 +238,8 @@ extern "C" int bevf_split_weights_f32x3(const float* w, void* planes, size_t n, 
 
 extern "C" int bevf_conv2d_nhwc_f32x3(const bevf_conv_desc* d, void* stream) {
   BEVF_REQUIRE(d && d->x && d->w, "conv f32x3: null x/w");
-  BEVF_REQUIRE(d->y && !d->colmax, "conv f32x3: needs y, no colmax");
+  BEVF_REQUIRE(d->y || d->colmax, "conv f32x3: needs y or colmax");
+  BEVF_REQUIRE(!d->colmax || (d->rows_per_group > 0 && d->relu), "conv f32x3: colmax needs rows_per_group > 0 and relu (the max is taken over max(v, 0))");
   BEVF_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->Cout > 0, "conv f32x3: empty shape");
   BEVF_REQUIRE(d->Cin > 0 && d->Cin % BK == 0, "conv f32x3: Cin=%d must be a positive multiple of %d", d->Cin, BK);
   BEVF_REQUIRE(d->x_cs >= d->Cin && d->x_cs % 4 == 0, "conv f32x3: x_cs=%d must be >= Cin and a multiple of 4", d->x_cs);
@@ -255,11 +256,11 @@ extern "C" int bevf_conv2d_nhwc_f32x3(const bevf_conv_desc* d, void* stream) {
   const long long M = (long long)d->N * d->Ho * d->Wo;
   BEVF_REQUIRE(M < (1ll << 31), "conv f32x3: pixel count overflows int32");
   ConvArgs a;
-  a.x = d->x; a.w = d->w; a.scale = d->scale; a.shift = d->shift; a.res = d->res; a.y = d->y; a.colmax = nullptr;
+  a.x = d->x; a.w = d->w; a.scale = d->scale; a.shift = d->shift; a.res = d->res; a.y = d->y; a.colmax = d->colmax;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.x_cs = d->x_cs;
   a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.y_cs = d->y_cs; a.res_cs = d->res_cs;
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
-  a.relu = d->relu; a.rows_per_group = 0;
+  a.relu = d->relu; a.rows_per_group = d->rows_per_group;
   a.M = (int)M; a.K = d->KH * d->KW * d->Cin; a.tilesM = a.tilesN = 0;
   a.m_split = 0; a.nbig = 0; a.tilesN_big = 0;
   fastdiv_make(d->Ho * d->Wo, &a.div_hw_mul, &a.div_hw_sh);

@@ -59,10 +59,12 @@ def set_conv_mode(mode: str) -> None:
     layer as "f32".  "f32": v_mfma_f32_32x32x2_f32 everywhere, an exact fp32 FMA chain whose bits do not depend on
     tile shapes.  "f32x3": opt-in, fp32 operands split exactly into three bf16 planes and multiplied on the bf16 MFMA
     (six partial products, fp32 accumulate; csrc/conv_split.hip) -- fp32-level error, ~1.3-1.4x faster, not
-    bit-identical to the default.  Engines repack on the next forward."""
+    bit-identical to the default.  "wino_x3": opt-in, both reductions of MFMA work together -- Winograd where "wino" uses it,
+    the three-plane kernel for every other layer (stride-2 3x3, 1x1 projections, PointNet incl. its fused point max).
+    Engines repack on the next forward."""
     global _CONV_MODE
-    if mode not in ("f32", "wino", "f32x3"):
-        raise ValueError(f"conv mode must be 'f32', 'wino' or 'f32x3', got {mode!r}")
+    if mode not in ("f32", "wino", "f32x3", "wino_x3"):
+        raise ValueError(f"conv mode must be 'f32', 'wino', 'f32x3' or 'wino_x3', got {mode!r}")
     _CONV_MODE = mode
 
 
@@ -72,8 +74,8 @@ def conv_mode() -> str:
 
 def pack_conv(conv, bn=None, relu: bool = True, split_ok: bool = True, wino_ok: bool = True) -> PackedConv:
     """Weights keep the module's storage dtype (fp32 or bf16); the folded BN scale/shift are always fp32.
-    In "f32x3" mode fp32 filters with Cin % 32 == 0 are stored as three bf16 planes (split_ok=False: layers whose
-    launch needs what the f32x3 kernel lacks, i.e. the fused column max)."""
+    In "f32x3" / "wino_x3" mode fp32 filters with Cin % 32 == 0 are stored as three bf16 planes (split_ok=False keeps a layer
+    on the exact kernel)."""
     w = conv.weight.detach()
     if w.dim() == 3:                                   # Conv1d k=1 == pointwise
         w = w.unsqueeze(-1)
@@ -89,9 +91,9 @@ def pack_conv(conv, bn=None, relu: bool = True, split_ok: bool = True, wino_ok: 
 def _finish_pack(packed, scale, shift, cin, cout, k, stride, pad, relu, split_ok=True, wino_ok=True) -> PackedConv:
     """OHWI filter -> what the active conv mode's kernel reads."""
     if packed.dtype == torch.float32 and cin % 32 == 0:
-        if _CONV_MODE == "wino" and wino_ok and (k, stride, pad) == (3, 1, 1):
+        if _CONV_MODE in ("wino", "wino_x3") and wino_ok and (k, stride, pad) == (3, 1, 1):
             return PackedConv(L.wino_filter_transform(packed, cout, cin), scale, shift, cin, cout, k, stride, pad, relu, wino=True)
-        if _CONV_MODE == "f32x3" and split_ok:
+        if _CONV_MODE in ("f32x3", "wino_x3") and split_ok:
             packed = L.split_weights_f32x3(packed)
     return PackedConv(packed, scale, shift, cin, cout, k, stride, pad, relu)
 
@@ -316,8 +318,7 @@ class PointNetEngine(_Engine):
         self.w0 = w0.reshape(w0.shape[0], self.cin).float().contiguous()
         self.s0, self.b0 = _bn_fold(convs[0].bias, bns[0], w0.shape[0], w0.device)
         self.c0 = w0.shape[0]
-        n = len(convs) - 1                            # the last layer fuses the max over points (colmax): exact kernel
-        self.layers = [pack_conv(c, b, True, split_ok=i < n - 1) for i, (c, b) in enumerate(zip(convs[1:], bns[1:]))]
+        self.layers = [pack_conv(c, b, True) for c, b in zip(convs[1:], bns[1:])]   # the last layer fuses the max over points (colmax)
 
     def run(self, pts: torch.Tensor, keep_last: bool = False):
         """pts: (B,N,C) contiguous -> (B, feat) global max feature [and the (B*N, feat) last activations].

@@ -32,6 +32,17 @@ def test_full_size_frame_matches_oracle(gpu, model_and_frame):
         assert tuple(out[k].shape) == tuple(ref[k].shape)
         e = rel_err(out[k].cpu(), ref[k])
         assert e <= 1e-4, (k, e)                        # north_star: fp32 features / logits within 1e-4 rel
+    # the opt-in mixed mode (Winograd + three-plane bf16 split for the other layers) holds the same bound at full size
+    from bevfusion_multimodal_3d_object_detection_amd import engine
+    default = engine.conv_mode()
+    engine.set_conv_mode("wino_x3")
+    try:
+        mixed = {k: v.clone() for k, v in m(imgs.cuda(), pts.cuda(), None).items()}
+    finally:
+        engine.set_conv_mode(default)
+    for k in ref:
+        e = rel_err(mixed[k].cpu(), ref[k])
+        assert e <= 1e-4, (k, e, "wino_x3")
 
 
 def test_batching_is_bitwise_invariant(gpu, model_and_frame):

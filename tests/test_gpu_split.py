@@ -87,3 +87,57 @@ def test_detector_in_f32x3_mode_matches_oracle_like_fp32(gpu):
         assert rel_err(split[k].cpu(), ref[k]) <= 1e-4, k
         assert rel_err(split[k].cpu(), exact[k].cpu()) <= 2e-5, k
         assert torch.equal(again[k], exact[k]), k                                      # back to the exact kernels
+
+
+def test_f32x3_conv_with_fused_column_max(gpu):
+    """The three-plane kernel with the fused max over each group of rows (PointNet's last layer: no activation written),
+    against the exact kernel's column max and an fp64 reference."""
+    M, P, cin, cout = 6 * 500, 500, 64, 160
+    x = synth.normal((M, cin), 41).relu()
+    w = synth.normal((cout, cin), 42, 0, (2.0 / cin) ** 0.5)
+    scale, shift = synth.uniform((cout,), 43, 0.5, 1.5), synth.normal((cout,), 44, 0, 0.3)
+    ref = ((x.double() @ w.double().t()) * scale.double() + shift.double()).relu().view(M // P, P, cout).amax(1)
+    out = {}
+    for split in (False, True):
+        wg = w.contiguous().view(-1).cuda()
+        if split:
+            wg = L.split_weights_f32x3(wg)
+        gmax = torch.zeros(M // P, cout, dtype=torch.int32, device=gpu)
+        L.conv2d_nhwc(x.view(-1).cuda(), wg, scale.cuda(), shift.cuda(), None, N=M, H=1, W=1, Cin=cin, x_cs=cin, Cout=cout, y_cs=cout,
+                      KH=1, KW=1, stride=1, pad=0, relu=True, colmax=gmax, rows_per_group=P)
+        out[split] = gmax.view(torch.float32).cpu()
+    from tests.conftest import rel_err
+    assert rel_err(out[True], ref) <= 2e-6 and rel_err(out[False], ref) <= 2e-6
+    assert rel_err(out[True], out[False]) <= 2e-6
+
+
+def test_detector_in_wino_x3_mode_matches_oracle(gpu):
+    """Opt-in mixed mode: Winograd for the 3x3 / stride 1 layers, the three-plane kernel for every other convolution (stride-2,
+    1x1, PointNet incl. its fused point max): within the same 1e-4 of the CPU oracle, 2e-5 of the default mode."""
+    from bevfusion_multimodal_3d_object_detection_amd import engine, fusion
+    from oracle import ref_model
+    from tests.conftest import rel_err
+    m = fusion.create_detector("camera+lidar+radar", "bev", "centernet", bev_h=50, bev_w=50)
+    synth.fill_state_dict_(m, 6)
+    imgs, pts, radars = synth.frame_inputs(2, 2, 96, 160, 700, 4, n_radars=5, seed=11)
+    ora = ref_model.make_detector("camera+lidar+radar", 50, 50)
+    ora.load_state_dict(m.state_dict())
+    ora.eval()
+    with torch.no_grad():
+        ref = ora(imgs, pts, radars)
+    m = m.cuda().eval()
+    rad = [r.cuda() for r in radars] if radars is not None else None
+    default = engine.conv_mode()
+    try:
+        engine.set_conv_mode("wino")
+        base = {k: v.clone() for k, v in m(imgs.cuda(), pts.cuda(), rad).items()}
+        engine.set_conv_mode("wino_x3")
+        mixed = {k: v.clone() for k, v in m(imgs.cuda(), pts.cuda(), rad).items()}
+        eng = m.camera_encoder._engine
+        assert eng.blocks[0][0].wino and eng.proj.w.dtype == torch.bfloat16               # Winograd kept, the 1x1 projection repacked as planes
+        assert m.lidar_encoder._engine.layers[-1].w.dtype == torch.bfloat16                # PointNet's max layer too
+    finally:
+        engine.set_conv_mode(default)
+    for k in ref:
+        assert rel_err(mixed[k].cpu(), ref[k]) <= 1e-4, k
+        assert rel_err(mixed[k].cpu(), base[k].cpu()) <= 2e-5, k
