@@ -106,7 +106,7 @@ def _image_chunk(N: int, *per_image_elems: int) -> int:
 def _wino_ok(cin, k, stride, pad) -> bool:
     """The fused fp32 Winograd kernel (csrc/conv_wino.hip) serves the 3x3 / stride 1 / pad 1 layers when the conv mode
     says so (engine.set_conv_mode("wino")): forward and data-gradient convolutions of the training step alike."""
-    return E.conv_mode() == "wino" and (k, stride, pad) == (3, 1, 1) and cin % 32 == 0
+    return E.conv_mode() in ("wino", "wino_x3") and (k, stride, pad) == (3, 1, 1) and cin % 32 == 0      # (the split kernels are inference-only)
 
 
 def _conv_launch(x, w_ohwi, bias, y, n, H, W, cin, cout, k, stride, pad, relu, res=None, stats=None):
