@@ -377,6 +377,123 @@ __global__ __launch_bounds__(256) void gmax_bn_scatter(const float* __restrict__
   dx[((size_t)b * P + idx[i]) * cs + c] += (gamma ? gamma[c] : 1.f) * invstd[c] * dgm[i];
 }
 
+// ---- BatchNorm(+ReLU) backward fed by a 3x3/s2 max-pool backward (the ResNet stem in training) -----------------------------
+// dY of the dense stem map [N][H][W][C] is never materialised: each pass gathers it from the pooled gradient and the saved
+// argmax codes (the <= 4 windows that contain a pixel, in the order of train_misc.hip: maxpool_bwd, so the values -- and with
+// the loop structure of bn_bwd_partials / bn_bwd_apply the sums and dx -- are bit-identical to the unfused chain).  The ReLU
+// mask is recomputed from the raw input with the forward's fma.  Traffic at 48 images of 448x800: 9.2 GB -> 4 GB.
+__device__ __forceinline__ f32x4 pool_gather(const float* __restrict__ dpool, const unsigned char* __restrict__ idx, long long m,
+                                             int c, int H, int W, int C, int Ho, int Wo) {
+  const int iw = (int)(m % W);
+  const long long t = m / W;
+  const int ih = (int)(t % H), n = (int)(t / H);
+  f32x4 g = {0.f, 0.f, 0.f, 0.f};
+  for (int oh = ih / 2; oh <= (ih + 1) / 2; ++oh) {                            // 2*oh-1 <= ih <= 2*oh+1
+    if (oh >= Ho) continue;
+    const int dh = ih - (2 * oh - 1);
+    for (int ow = iw / 2; ow <= (iw + 1) / 2; ++ow) {
+      if (ow >= Wo) continue;
+      const unsigned code = (unsigned)(dh * 3 + (iw - (2 * ow - 1)));
+      const size_t o = ((size_t)(n * Ho + oh) * Wo + ow) * C + c;
+      const unsigned id4 = *reinterpret_cast<const unsigned*>(idx + o);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(dpool + o);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (((id4 >> (8 * j)) & 0xff) == code) g[j] += d[j];
+    }
+  }
+  return g;
+}
+
+__global__ __launch_bounds__(256) void pool_bn_bwd_partials(const float* __restrict__ dpool, const unsigned char* __restrict__ idx,
+                                                             const float* __restrict__ x, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ part,
+                                                             long long M, int H, int W, int C, int Ho, int Wo) {
+  extern __shared__ float red[];
+  const int c4 = C >> 2;                                                       // host: c4 <= 256 and 256 % c4 == 0
+  const int lanes = 256 / c4, cq = threadIdx.x % c4, rl = threadIdx.x / c4;
+  float mu[4], is[4], fa[4], fb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    mu[j] = mean[cq * 4 + j];
+    is[j] = invstd[cq * 4 + j];
+    fa[j] = (gamma ? gamma[cq * 4 + j] : 1.f) * is[j];
+    fb[j] = (beta ? beta[cq * 4 + j] : 0.f) - mu[j] * fa[j];
+  }
+  float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+  const long long step = (long long)gridDim.x * lanes;
+  long long m = (long long)blockIdx.x * lanes + rl;
+  auto one = [&](long long r, const f32x4 xv) {
+    f32x4 g = pool_gather(dpool, idx, r, cq * 4, H, W, C, Ho, Wo);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      g[j] = fmaf(xv[j], fa[j], fb[j]) > 0.f ? g[j] : 0.f;
+      a1[j] += g[j];
+      a2[j] = fmaf(g[j], (xv[j] - mu[j]) * is[j], a2[j]);
+    }
+  };
+  for (; m + 3 * step < M; m += 4 * step) {
+    f32x4 xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xv[u] = *reinterpret_cast<const f32x4*>(x + (size_t)(m + u * step) * C + cq * 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) one(m + u * step, xv[u]);
+  }
+  for (; m < M; m += step) one(m, *reinterpret_cast<const f32x4*>(x + (size_t)m * C + cq * 4));
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[threadIdx.x * 8 + j] = a1[j]; red[threadIdx.x * 8 + 4 + j] = a2[j]; }
+  __syncthreads();
+  if ((int)threadIdx.x < c4) {
+    float t1[4] = {0, 0, 0, 0}, t2[4] = {0, 0, 0, 0};
+    for (int r = 0; r < lanes; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        t1[j] += red[(r * c4 + threadIdx.x) * 8 + j];
+        t2[j] += red[(r * c4 + threadIdx.x) * 8 + 4 + j];
+      }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      part[((size_t)blockIdx.x * C + threadIdx.x * 4 + j) * 2] = t1[j];
+      part[((size_t)blockIdx.x * C + threadIdx.x * 4 + j) * 2 + 1] = t2[j];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pool_bn_bwd_apply(const float* __restrict__ dpool, const unsigned char* __restrict__ idx,
+                                                          const float* __restrict__ x, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ s_dy,
+                                                          const float* __restrict__ s_dyx, float* __restrict__ dx, long long M,
+                                                          int H, int W, int C, int Ho, int Wo) {
+  const int c4 = C >> 2;
+  const int lanes = 256 / c4, cq = threadIdx.x % c4, rl = threadIdx.x / c4, c = cq * 4;
+  const long long step = (long long)gridDim.x * lanes;
+  const float invM = 1.f / (float)M;
+  float gi[4], is[4], mu[4], sd[4], sx[4], fa[4], fb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    is[j] = invstd[c + j];
+    mu[j] = mean[c + j];
+    gi[j] = (gamma ? gamma[c + j] : 1.f) * is[j];
+    fa[j] = gi[j];
+    fb[j] = (beta ? beta[c + j] : 0.f) - mu[j] * fa[j];
+    sd[j] = s_dy[c + j] * invM;
+    sx[j] = s_dyx[c + j] * invM;
+  }
+  for (long long m = (long long)blockIdx.x * lanes + rl; m < M; m += step) {
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)m * C + c);
+    f32x4 g = pool_gather(dpool, idx, m, c, H, W, C, Ho, Wo);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      g[j] = fmaf(xv[j], fa[j], fb[j]) > 0.f ? g[j] : 0.f;
+      o[j] = gi[j] * (g[j] - sd[j] - (xv[j] - mu[j]) * is[j] * sx[j]);
+    }
+    *reinterpret_cast<f32x4*>(dx + (size_t)m * C + c) = o;
+  }
+}
+
 static inline unsigned row_grid(long long M, int C) {      // workgroups for the row-streaming kernels
   const int lanes = C / 4 >= 256 ? 1 : 256 / (C / 4);
   long long g = (M + (long long)lanes * 4 - 1) / ((long long)lanes * 4);
@@ -464,6 +581,31 @@ extern "C" int bevf_bn_backward_from_partials_f32(const float* dy, const float* 
     hipLaunchKernelGGL(bn_bwd_apply, dim3(row_grid(M, C)), dim3(256), 0, st, dy, x, mean, invstd, gamma, dbeta, dgamma, dx,
                        (long long)M, C, cs);
   return bevf_check_launch("bevf_bn_backward_from_partials_f32");
+}
+
+// BatchNorm(+ReLU) backward whose dY comes out of a 3x3/s2/p1 max-pool backward (the ResNet stem, ref src/encoders.py:154-157 in
+// training): dpool [N][Ho][Wo][C] gradient of the pooled map, idx the argmax codes of bevf_maxpool3x3s2_idx_f32, x the raw conv
+// output [N][H][W][C].  Bit-identical to bevf_maxpool3x3s2_bwd_f32 followed by bevf_bn_backward_f32(relu = 1, y = NULL) without the
+// dense dY in HBM.
+extern "C" int bevf_pool_bn_backward_f32(const float* dpool, const uint8_t* idx, const float* x, const float* mean,
+                                         const float* invstd, const float* gamma, const float* beta, float* work, float* dgamma,
+                                         float* dbeta, float* dx, int N, int H, int W, int C, void* stream) {
+  BEVF_REQUIRE(dpool && idx && x && mean && invstd && work && dgamma && dbeta && dx, "pool_bn_backward: null pointer");
+  BEVF_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0,
+               "pool_bn_backward: C=%d must be a multiple of 4 with 256 %% (C/4) == 0", C);
+  BEVF_REQUIRE(bevf_aligned16(dpool) && bevf_aligned16(x) && bevf_aligned16(dx), "pool_bn_backward: unaligned");
+  const long long M = (long long)N * H * W;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int lanes = 256 / (C / 4);
+  long long G = (M + lanes - 1) / lanes;
+  if (G > kStatGrid) G = kStatGrid;
+  hipLaunchKernelGGL(pool_bn_bwd_partials, dim3((unsigned)G), dim3(256), 256 * 8 * sizeof(float), st, dpool, idx, x, mean, invstd, gamma,
+                     beta, work, M, H, W, C, Ho, Wo);
+  hipLaunchKernelGGL(sums_finalize, dim3(C), dim3(256), 0, st, work, dbeta, dgamma, C, (int)G);
+  hipLaunchKernelGGL(pool_bn_bwd_apply, dim3(row_grid(M, C)), dim3(256), 0, st, dpool, idx, x, mean, invstd, gamma, beta, dbeta, dgamma,
+                     dx, M, H, W, C, Ho, Wo);
+  return bevf_check_launch("bevf_pool_bn_backward_f32");
 }
 
 // Backward of y = relu(batchnorm(x)) followed by a max over the P rows of each of B groups (ref src/encoders.py:296-299

@@ -349,6 +349,7 @@ def bn_train_backward(dy, s: _BNState, bn, relu=True, need_dx=True):
     return dx, dgamma[:s.C], dbeta[:s.C]
 
 
+FUSE_POOL_BN_BACKWARD = True  # stem: max-pool backward gathered inside the BatchNorm backward passes (no dense 1.1 GB dY)
 FUSE_BN_BACKWARD = False     # the producing data-gradient conv does the next BatchNorm's first backward pass in its epilogue: correct
                              # (tests run both settings) but +0.4 ms per step on MI355X, because the Winograd epilogue is exposed time
 
@@ -664,10 +665,22 @@ class DetectorTape:
             if i % 2 == 1:
                 sink.ready()                                   # one ResNet stage done: its gradients can travel
         N, H1, W1 = self.pool_geom
-        dpool_in = _new(N * H1 * W1 * 64, d.device)
-        _ck(_lib().bevf_maxpool3x3s2_bwd_f32(d.data_ptr(), self.pool_idx.data_ptr(), dpool_in.data_ptr(), N, H1, W1, 64, _st()),
-            "bevf_maxpool3x3s2_bwd_f32")
-        draw, dgamma, dbeta = bn_train_backward(dpool_in, self.stem_bn, enc.bn1, relu=True)
+        if FUSE_POOL_BN_BACKWARD:
+            # max-pool backward + BatchNorm/ReLU backward in one pair of passes: the dense dY of the stem map (1.1 GB at 48 images of
+            # 448x800) is gathered from the pooled gradient on the fly, never written (bit-identical to the two-kernel chain below)
+            s = self.stem_bn
+            work = _new(_lib().bevf_bn_work_floats(64), d.device)
+            dgamma, dbeta, draw = _new(64, d.device), _new(64, d.device), _new(N * H1 * W1 * 64, d.device)
+            g = enc.bn1.weight.data_ptr() if enc.bn1.weight is not None else None
+            b = enc.bn1.bias.data_ptr() if enc.bn1.bias is not None else None
+            _ck(_lib().bevf_pool_bn_backward_f32(d.data_ptr(), self.pool_idx.data_ptr(), s.xraw.data_ptr(), s.mean.data_ptr(),
+                                                 s.invstd.data_ptr(), g, b, work.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                                 draw.data_ptr(), N, H1, W1, 64, _st()), "bevf_pool_bn_backward_f32")
+        else:
+            dpool_in = _new(N * H1 * W1 * 64, d.device)
+            _ck(_lib().bevf_maxpool3x3s2_bwd_f32(d.data_ptr(), self.pool_idx.data_ptr(), dpool_in.data_ptr(), N, H1, W1, 64, _st()),
+                "bevf_maxpool3x3s2_bwd_f32")
+            draw, dgamma, dbeta = bn_train_backward(dpool_in, self.stem_bn, enc.bn1, relu=True)
         sink.add(enc.bn1.weight, dgamma)
         sink.add(enc.bn1.bias, dbeta)
         # stem weight gradient: direct MFMA kernel on the image patches (no im2col matrix), dW as [64][160]

@@ -402,6 +402,12 @@ int bevf_bn_backward_f32(float* dy, const float* y, const float* x, const float*
 int bevf_bn_backward_from_partials_f32(const float* dy, const float* x, const float* mean, const float* invstd,
                                        const float* gamma, const float* part, int G, float* dgamma, float* dbeta, float* dx,
                                        int M, int C, int cs, void* stream);
+/* BatchNorm(+ReLU) backward whose dY is the backward of a 3x3/s2/p1 max-pool (the ResNet stem in training, ref
+ * src/encoders.py:154-157): dpool [N][Ho][Wo][C], idx from bevf_maxpool3x3s2_idx_f32, x the raw conv output [N][H][W][C].
+ * Bit-identical to bevf_maxpool3x3s2_bwd_f32 + bevf_bn_backward_f32(relu = 1, y = NULL); the dense dY never exists.       */
+int bevf_pool_bn_backward_f32(const float* dpool, const uint8_t* idx, const float* x, const float* mean, const float* invstd,
+                              const float* gamma, const float* beta, float* work, float* dgamma, float* dbeta, float* dx,
+                              int N, int H, int W, int C, void* stream);
 
 int bevf_add_inplace_f32(float* y, const float* x, size_t n, void* stream);            /* y += x            */
 int bevf_relu_mask_f32(float* dy, const float* y, size_t n, void* stream);             /* dy *= (y > 0)     */

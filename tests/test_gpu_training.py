@@ -504,3 +504,39 @@ def test_checkpoint_roundtrip_and_torch_adamw_compatibility(gpu, tmp_path):
     for pa, pb, pc in zip(a.parameters(), b.parameters(), c.parameters()):
         assert torch.equal(pa, pb)
         assert rel_err(pc.detach().cpu(), pa.detach().cpu()) <= 2e-6
+
+
+@pytest.mark.parametrize("N,H,W,C", [(2, 9, 13, 64), (1, 16, 16, 64), (3, 7, 10, 32), (1, 1, 1, 64), (2, 112, 200, 64)])
+def test_pool_bn_backward_is_bit_identical_to_the_two_kernel_chain(gpu, N, H, W, C):
+    """bevf_pool_bn_backward_f32 (stem in training: max-pool backward gathered inside the BatchNorm/ReLU backward passes, ref
+    src/encoders.py:154-157 under loss.backward()) against bevf_maxpool3x3s2_bwd_f32 -> bevf_bn_backward_f32: dgamma, dbeta and
+    dx must be the same bits (same gather order, same loop structure)."""
+    lib = L.lib()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    M = N * H * W
+    x = synth.normal((M * C,), 70 + H).cuda()
+    mean, var = synth.normal((C,), 71, 0, 0.2).cuda(), synth.uniform((C,), 72, 0.5, 2.0).cuda()
+    invstd = (var + 1e-5).rsqrt()
+    gamma, beta = synth.uniform((C,), 73, 0.5, 1.5).cuda(), synth.normal((C,), 74, 0, 0.3).cuda()
+    y = torch.empty(M * C, device=gpu)
+    assert lib.bevf_bn_apply_f32(x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None,
+                                 y.data_ptr(), M, C, C, 1, None) == 0
+    pooled = torch.empty(N * Ho * Wo * C, device=gpu)
+    idx = torch.empty(N * Ho * Wo * C, dtype=torch.uint8, device=gpu)
+    assert lib.bevf_maxpool3x3s2_idx_f32(y.data_ptr(), pooled.data_ptr(), idx.data_ptr(), N, H, W, C, None) == 0
+    dpool = synth.normal((N * Ho * Wo * C,), 75).cuda()
+    work = torch.empty(lib.bevf_bn_work_floats(C), device=gpu)
+    # unfused chain
+    dy = torch.empty(M * C, device=gpu)
+    assert lib.bevf_maxpool3x3s2_bwd_f32(dpool.data_ptr(), idx.data_ptr(), dy.data_ptr(), N, H, W, C, None) == 0
+    dg0, db0, dx0 = torch.empty(C, device=gpu), torch.empty(C, device=gpu), torch.empty(M * C, device=gpu)
+    assert lib.bevf_bn_backward_f32(dy.data_ptr(), None, x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                                    beta.data_ptr(), work.data_ptr(), dg0.data_ptr(), db0.data_ptr(), dx0.data_ptr(), M, C, C, 1,
+                                    None) == 0
+    # fused
+    dg1, db1 = torch.empty(C, device=gpu), torch.empty(C, device=gpu)
+    dx1 = torch.full((M * C,), float("nan"), device=gpu)
+    assert lib.bevf_pool_bn_backward_f32(dpool.data_ptr(), idx.data_ptr(), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                         gamma.data_ptr(), beta.data_ptr(), work.data_ptr(), dg1.data_ptr(), db1.data_ptr(),
+                                         dx1.data_ptr(), N, H, W, C, None) == 0
+    assert torch.equal(dg0, dg1) and torch.equal(db0, db1) and torch.equal(dx0, dx1)
