@@ -157,6 +157,7 @@ SIGNATURES = {
     "bevf_gmax_bn_backward_f32": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_bn_backward_f32": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_pool_bn_backward_f32": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 4 + [C.c_void_p]),
+    "bevf_bn_relu_maxpool3x3s2_idx_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_add_inplace_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "bevf_relu_mask_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "bevf_maxpool3x3s2_idx_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),

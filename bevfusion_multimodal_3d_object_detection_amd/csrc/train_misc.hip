@@ -60,6 +60,50 @@ __global__ __launch_bounds__(256) void maxpool_fwd_idx(const float* __restrict__
         (unsigned)best[0] | ((unsigned)best[1] << 8) | ((unsigned)best[2] << 16) | ((unsigned)best[3] << 24);
   }
 }
+// max-pool over relu(batchnorm(x)) evaluated on the fly (the ResNet stem in training): the normalised 64-channel stem map -- the
+// largest activation of the step -- is never written; values and argmax codes are those of bn_apply (same fma, same max(t, 0))
+// followed by maxpool_fwd_idx
+__global__ __launch_bounds__(256) void bn_relu_maxpool_idx(const float* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            unsigned char* __restrict__ idx, int N, int H, int W, int C, int Ho,
+                                                            int Wo) {
+  const int c4 = C >> 2;
+  const long long total = (long long)N * Ho * Wo * c4;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % c4) * 4;
+    long long pix = i / c4;
+    const int ow = (int)(pix % Wo);
+    pix /= Wo;
+    const int oh = (int)(pix % Ho), n = (int)(pix / Ho);
+    float a[4], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      a[j] = (gamma ? gamma[c + j] : 1.f) * invstd[c + j];
+      b[j] = (beta ? beta[c + j] : 0.f) - mean[c + j] * a[j];
+    }
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int best[4] = {0, 0, 0, 0};
+    for (int dh = 0; dh < 3; ++dh) {
+      const int ih = 2 * oh - 1 + dh;
+      if ((unsigned)ih >= (unsigned)H) continue;
+      for (int dw = 0; dw < 3; ++dw) {
+        const int iw = 2 * ow - 1 + dw;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + ((size_t)(n * H + ih) * W + iw) * C + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = fmaxf(fmaf(xv[j], a[j], b[j]), 0.f);
+          if (v > m[j] || (v != v)) { m[j] = v; best[j] = dh * 3 + dw; }
+        }
+      }
+    }
+    *reinterpret_cast<f32x4*>(y + (size_t)i * 4) = m;
+    *reinterpret_cast<unsigned*>(idx + (size_t)i * 4) =
+        (unsigned)best[0] | ((unsigned)best[1] << 8) | ((unsigned)best[2] << 16) | ((unsigned)best[3] << 24);
+  }
+}
+
 __global__ __launch_bounds__(256) void maxpool_bwd(const float* __restrict__ dy, const unsigned char* __restrict__ idx,
                                                     float* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo) {
   const int c4 = C >> 2;
@@ -534,6 +578,16 @@ extern "C" int bevf_maxpool3x3s2_idx_f32(const float* x, float* y, uint8_t* idx,
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   hipLaunchKernelGGL(maxpool_fwd_idx, dim3(ew_grid((long long)N * Ho * Wo * (C / 4))), dim3(256), 0, ST, x, y, idx, N, H, W, C, Ho, Wo);
   return bevf_check_launch("bevf_maxpool3x3s2_idx_f32");
+}
+extern "C" int bevf_bn_relu_maxpool3x3s2_idx_f32(const float* x, const float* mean, const float* invstd, const float* gamma,
+                                                 const float* beta, float* y, uint8_t* idx, int N, int H, int W, int C,
+                                                 void* stream) {
+  BEVF_REQUIRE(x && mean && invstd && y && idx && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0,
+               "bn_relu_maxpool_idx: bad arguments (C %% 4)");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  hipLaunchKernelGGL(bn_relu_maxpool_idx, dim3(ew_grid((long long)N * Ho * Wo * (C / 4))), dim3(256), 0, ST, x, mean, invstd, gamma, beta,
+                     y, idx, N, H, W, C, Ho, Wo);
+  return bevf_check_launch("bevf_bn_relu_maxpool3x3s2_idx_f32");
 }
 extern "C" int bevf_maxpool3x3s2_bwd_f32(const float* dy, const uint8_t* idx, float* dx, int N, int H, int W, int C,
                                          void* stream) {

@@ -349,7 +349,8 @@ def bn_train_backward(dy, s: _BNState, bn, relu=True, need_dx=True):
     return dx, dgamma[:s.C], dbeta[:s.C]
 
 
-FUSE_POOL_BN_BACKWARD = True  # stem: max-pool backward gathered inside the BatchNorm backward passes (no dense 1.1 GB dY)
+FUSE_POOL_BN_BACKWARD = True  # stem: BatchNorm + ReLU evaluated inside the max-pool (forward) and the max-pool backward gathered inside
+                              # the BatchNorm backward passes: neither the normalised map nor its gradient (1.1 GB each) is ever written
 FUSE_BN_BACKWARD = False     # the producing data-gradient conv does the next BatchNorm's first backward pass in its epilogue: correct
                              # (tests run both settings) but +0.4 ms per step on MI355X, because the Winograd epilogue is exposed time
 
@@ -620,12 +621,23 @@ class DetectorTape:
         one, zero = torch.ones(64, device=dev), torch.zeros(64, device=dev)
         raw = _new(N * H1 * W1 * 64, dev)
         L.stem_conv7x7(x, packed.view(-1), one, zero, raw, N, H, W, relu=False)
-        y, self.stem_bn = bn_train_forward(raw, enc.bn1, N * H1 * W1, 64, relu=True)
         H2, W2 = (H1 - 1) // 2 + 1, (W1 - 1) // 2 + 1
         pooled = _new(N * H2 * W2 * 64, dev)
         self.pool_idx = torch.empty(N * H2 * W2 * 64, dtype=torch.uint8, device=dev)
-        _ck(_lib().bevf_maxpool3x3s2_idx_f32(y.data_ptr(), pooled.data_ptr(), self.pool_idx.data_ptr(), N, H1, W1, 64, _st()),
-            "bevf_maxpool3x3s2_idx_f32")
+        if FUSE_POOL_BN_BACKWARD:
+            # statistics only; BatchNorm + ReLU are evaluated inside the max-pool: the normalised stem map (1.1 GB) is never written --
+            # nothing downstream reads it (the backward recomputes the ReLU mask from the raw conv output)
+            _, self.stem_bn = bn_train_forward(raw, enc.bn1, N * H1 * W1, 64, relu=True, apply=False)
+            s = self.stem_bn
+            g = enc.bn1.weight.data_ptr() if enc.bn1.weight is not None else None
+            b = enc.bn1.bias.data_ptr() if enc.bn1.bias is not None else None
+            _ck(_lib().bevf_bn_relu_maxpool3x3s2_idx_f32(raw.data_ptr(), s.mean.data_ptr(), s.invstd.data_ptr(), g, b, pooled.data_ptr(),
+                                                         self.pool_idx.data_ptr(), N, H1, W1, 64, _st()),
+                "bevf_bn_relu_maxpool3x3s2_idx_f32")
+        else:
+            y, self.stem_bn = bn_train_forward(raw, enc.bn1, N * H1 * W1, 64, relu=True)
+            _ck(_lib().bevf_maxpool3x3s2_idx_f32(y.data_ptr(), pooled.data_ptr(), self.pool_idx.data_ptr(), N, H1, W1, 64, _st()),
+                "bevf_maxpool3x3s2_idx_f32")
         self.pool_geom = (N, H1, W1)
         cur, h, wd = pooled, H2, W2
         self.blocks = []

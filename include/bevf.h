@@ -408,6 +408,10 @@ int bevf_bn_backward_from_partials_f32(const float* dy, const float* x, const fl
 int bevf_pool_bn_backward_f32(const float* dpool, const uint8_t* idx, const float* x, const float* mean, const float* invstd,
                               const float* gamma, const float* beta, float* work, float* dgamma, float* dbeta, float* dx,
                               int N, int H, int W, int C, void* stream);
+/* Forward twin: y = maxpool3x3s2(relu(batchnorm(x))) with the argmax codes of bevf_maxpool3x3s2_idx_f32, the normalised map never
+ * written (bit-identical to bevf_bn_apply_f32(relu = 1) followed by bevf_maxpool3x3s2_idx_f32).                                */
+int bevf_bn_relu_maxpool3x3s2_idx_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                      float* y, uint8_t* idx, int N, int H, int W, int C, void* stream);
 
 int bevf_add_inplace_f32(float* y, const float* x, size_t n, void* stream);            /* y += x            */
 int bevf_relu_mask_f32(float* dy, const float* y, size_t n, void* stream);             /* dy *= (y > 0)     */

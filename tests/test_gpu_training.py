@@ -540,3 +540,26 @@ def test_pool_bn_backward_is_bit_identical_to_the_two_kernel_chain(gpu, N, H, W,
                                          gamma.data_ptr(), beta.data_ptr(), work.data_ptr(), dg1.data_ptr(), db1.data_ptr(),
                                          dx1.data_ptr(), N, H, W, C, None) == 0
     assert torch.equal(dg0, dg1) and torch.equal(db0, db1) and torch.equal(dx0, dx1)
+
+
+@pytest.mark.parametrize("N,H,W,C", [(2, 9, 13, 64), (1, 16, 16, 64), (3, 7, 10, 32), (1, 1, 1, 64), (2, 112, 200, 64)])
+def test_bn_relu_maxpool_forward_is_bit_identical_to_the_two_kernel_chain(gpu, N, H, W, C):
+    """bevf_bn_relu_maxpool3x3s2_idx_f32 against bevf_bn_apply_f32(relu) -> bevf_maxpool3x3s2_idx_f32: pooled values and argmax
+    codes must be the same bits (ties included: the first maximum wins in both)."""
+    lib = L.lib()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    M = N * H * W
+    x = synth.normal((M * C,), 80 + H).cuda()
+    mean, var = synth.normal((C,), 81, 0, 0.2).cuda(), synth.uniform((C,), 82, 0.5, 2.0).cuda()
+    invstd = (var + 1e-5).rsqrt()
+    gamma, beta = synth.uniform((C,), 83, 0.5, 1.5).cuda(), synth.normal((C,), 84, 0, 0.3).cuda()
+    y = torch.empty(M * C, device=gpu)
+    assert lib.bevf_bn_apply_f32(x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None,
+                                 y.data_ptr(), M, C, C, 1, None) == 0
+    p0, p1 = torch.empty(N * Ho * Wo * C, device=gpu), torch.full((N * Ho * Wo * C,), float("nan"), device=gpu)
+    i0 = torch.empty(N * Ho * Wo * C, dtype=torch.uint8, device=gpu)
+    i1 = torch.full((N * Ho * Wo * C,), 255, dtype=torch.uint8, device=gpu)
+    assert lib.bevf_maxpool3x3s2_idx_f32(y.data_ptr(), p0.data_ptr(), i0.data_ptr(), N, H, W, C, None) == 0
+    assert lib.bevf_bn_relu_maxpool3x3s2_idx_f32(x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                 p1.data_ptr(), i1.data_ptr(), N, H, W, C, None) == 0
+    assert torch.equal(p0, p1) and torch.equal(i0, i1)
