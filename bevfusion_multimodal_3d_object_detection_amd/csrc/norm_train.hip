@@ -201,13 +201,13 @@ __global__ __launch_bounds__(256) void bn_bwd_partials(float* __restrict__ dy, c
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (relu) {
-          if (relu == 2) {
+          if (relu >= 2) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) yy[u][j] = fmaf(xv[u][j], fa[j], fb[j]);
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j) g[u][j] = yy[u][j] > 0.f ? g[u][j] : 0.f;
-          *reinterpret_cast<f32x4*>(dy + (size_t)(m + u * step) * C + cq * 4) = g[u];
+          if (relu != 3) *reinterpret_cast<f32x4*>(dy + (size_t)(m + u * step) * C + cq * 4) = g[u];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partials(float* __restrict__ dy, c
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) g[j] = yy[j] > 0.f ? g[j] : 0.f;
-        *reinterpret_cast<f32x4*>(dy + (size_t)m * C + cq * 4) = g;
+        if (relu != 3) *reinterpret_cast<f32x4*>(dy + (size_t)m * C + cq * 4) = g;
       }
       if (x) {
         const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)m * cs + cq * 4);
@@ -283,11 +283,22 @@ __global__ __launch_bounds__(256) void sums_finalize(const float* __restrict__ p
 }
 
 // backward stage 2: dx = gamma*invstd * (dy - sum_dy/M - xhat * sum_dyx/M) = k1*dy + k2*x + k3 per channel
+// (contraction switched off: the kernels that share this formula -- bn_bwd_apply with and without re-masking, pool_bn_bwd_apply
+//  -- must agree bit for bit, which contraction decisions that depend on the surrounding code would not guarantee)
+__device__ __forceinline__ float bn_dx(float gi, float g, float sd, float x, float mu, float is, float sx) {
+#pragma clang fp contract(off)                         // (HIP's __fmul_rn / __fsub_rn are plain operators: they do not stop contraction)
+  const float t = ((x - mu) * is) * sx;
+  const float u = (g - sd) - t;
+  return gi * u;
+}
+// (remask: dy arrives WITHOUT the ReLU mask -- stage 1 ran in mode 3 and did not write it back -- and is masked here with the same
+//  recomputed fma(x, gamma*invstd, beta - mean*gamma*invstd) > 0)
 __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ s_dy,
                                                      const float* __restrict__ s_dyx, float* __restrict__ dx,
-                                                     long long M, int C, int cs) {
+                                                     long long M, int C, int cs, const float* __restrict__ beta = nullptr,
+                                                     int remask = 0) {
   const int c4 = C >> 2;
   const int lanes = c4 >= 256 ? 1 : 256 / c4;
   const int rl = c4 >= 256 ? 0 : threadIdx.x / c4;
@@ -296,12 +307,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dy
   const float invM = 1.f / (float)M;
   for (int cq = threadIdx.x % (c4 < 256 ? c4 : 256); cq < c4; cq += 256) {
     const int c = cq * 4;
-    float gi[4], is[4], mu[4], sd[4], sx[4];
+    float gi[4], is[4], mu[4], sd[4], sx[4], fb[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       is[j] = invstd[c + j];
       mu[j] = mean[c + j];
       gi[j] = (gamma ? gamma[c + j] : 1.f) * is[j];
+      fb[j] = (beta ? beta[c + j] : 0.f) - mu[j] * gi[j];
       sd[j] = s_dy[c + j] * invM;
       sx[j] = s_dyx[c + j] * invM;
     }
@@ -316,17 +328,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dy
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         f32x4 o;
+        if (remask) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = gi[j] * (g[u][j] - sd[j] - (xv[u][j] - mu[j]) * is[j] * sx[j]);
+          for (int j = 0; j < 4; ++j) g[u][j] = fmaf(xv[u][j], gi[j], fb[j]) > 0.f ? g[u][j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = bn_dx(gi[j], g[u][j], sd[j], xv[u][j], mu[j], is[j], sx[j]);
         *reinterpret_cast<f32x4*>(dx + (size_t)(m + u * step) * cs + c) = o;
       }
     }
     for (; m < M; m += step) {
-      const f32x4 g = dy ? *reinterpret_cast<const f32x4*>(dy + (size_t)m * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 g = dy ? *reinterpret_cast<const f32x4*>(dy + (size_t)m * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
       const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)m * cs + c);
       f32x4 o;
+      if (remask) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = gi[j] * (g[j] - sd[j] - (xv[j] - mu[j]) * is[j] * sx[j]);
+        for (int j = 0; j < 4; ++j) g[j] = fmaf(xv[j], gi[j], fb[j]) > 0.f ? g[j] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = bn_dx(gi[j], g[j], sd[j], xv[j], mu[j], is[j], sx[j]);
       *reinterpret_cast<f32x4*>(dx + (size_t)m * cs + c) = o;
     }
   }
@@ -488,7 +508,7 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_apply(const float* __restrict
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       g[j] = fmaf(xv[j], fa[j], fb[j]) > 0.f ? g[j] : 0.f;
-      o[j] = gi[j] * (g[j] - sd[j] - (xv[j] - mu[j]) * is[j] * sx[j]);
+      o[j] = bn_dx(gi[j], g[j], sd[j], xv[j], mu[j], is[j], sx[j]);
     }
     *reinterpret_cast<f32x4*>(dx + (size_t)m * C + c) = o;
   }
@@ -556,7 +576,10 @@ extern "C" int bevf_bn_backward_f32(float* dy, const float* y, const float* x, c
   BEVF_REQUIRE(!relu || y || (x && mean && invstd), "bn_backward: relu needs the forward output, or x/mean/invstd to recompute it");
   BEVF_REQUIRE(!dx || (x && mean && invstd && dgamma), "bn_backward: dx needs x, mean, invstd, dgamma");
   BEVF_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && cs >= C && cs % 4 == 0, "bn_backward: bad shape");
-  const int relu_mode = relu ? (y ? 1 : 2) : 0;          // y == NULL: mask recomputed from x (no residual in the forward)
+  // y == NULL: mask recomputed from x (no residual in the forward); relu == 2: additionally dy is left untouched (nobody reads the
+  // masked gradient of a layer without a skip connection) and the second pass masks again: one write of dy less
+  BEVF_REQUIRE(relu != 2 || (!y && x && mean && invstd), "bn_backward: relu = 2 recomputes the mask from x (y must be NULL)");
+  const int relu_mode = relu ? (y ? 1 : (relu == 2 ? 3 : 2)) : 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int lanes = C / 4 >= 256 ? 1 : 256 / (C / 4);
   int G = (M + lanes - 1) / lanes;
@@ -566,7 +589,7 @@ extern "C" int bevf_bn_backward_f32(float* dy, const float* y, const float* x, c
   hipLaunchKernelGGL(sums_finalize, dim3(C), dim3(256), 0, st, work, dbeta, dgamma, C, G);
   if (dx)
     hipLaunchKernelGGL(bn_bwd_apply, dim3(row_grid(M, C)), dim3(256), 0, st, dy, x, mean, invstd, gamma,
-                       dbeta, dgamma, dx, (long long)M, C, cs);
+                       dbeta, dgamma, dx, (long long)M, C, cs, beta, relu_mode == 3 ? 1 : 0);
   return bevf_check_launch("bevf_bn_backward_f32");
 }
 

@@ -333,7 +333,8 @@ def bn_train_forward(xraw, bn: nn.BatchNorm2d, M: int, Cc: int, res=None, relu=T
 
 
 def bn_train_backward(dy, s: _BNState, bn, relu=True, need_dx=True):
-    """In place: dy <- dy*(y>0).  Returns (dxraw or None, dgamma, dbeta)."""
+    """Returns (dxraw or None, dgamma, dbeta).  Layers with a skip connection: dy <- dy*(y>0) in place (it is the skip input's
+    gradient); layers without one: dy is left untouched (the mask is recomputed from the raw input in both passes)."""
     dev = dy.device
     work = _new(_lib().bevf_bn_work_floats(s.C), dev)
     dgamma, dbeta = _new(s.C, dev), _new(s.C, dev)
@@ -344,7 +345,8 @@ def bn_train_backward(dy, s: _BNState, bn, relu=True, need_dx=True):
     ymask = s.y.data_ptr() if (relu and s.has_res) else None
     _ck(_lib().bevf_bn_backward_f32(dy.data_ptr(), ymask, s.xraw.data_ptr(), s.mean.data_ptr(),
                                     s.invstd.data_ptr(), g, b, work.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-                                    dx.data_ptr() if dx is not None else None, s.M, s.C, s.C, int(relu), _st()),
+                                    dx.data_ptr() if dx is not None else None, s.M, s.C, s.C,
+                                    (1 if s.has_res else 2) if relu else 0, _st()),
         "bevf_bn_backward_f32")
     return dx, dgamma[:s.C], dbeta[:s.C]
 

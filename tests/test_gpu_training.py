@@ -563,3 +563,27 @@ def test_bn_relu_maxpool_forward_is_bit_identical_to_the_two_kernel_chain(gpu, N
     assert lib.bevf_bn_relu_maxpool3x3s2_idx_f32(x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                                  p1.data_ptr(), i1.data_ptr(), N, H, W, C, None) == 0
     assert torch.equal(p0, p1) and torch.equal(i0, i1)
+
+
+def test_bn_backward_without_write_back_is_bit_identical(gpu):
+    """bevf_bn_backward_f32 relu = 2 (mask recomputed in both passes, dy untouched) against relu = 1 with y = NULL (masked dy written
+    back, second pass reads it): same dgamma / dbeta / dx bits, and dy really stays as it was."""
+    lib = L.lib()
+    M, C = 5000, 96
+    x = synth.normal((M * C,), 90).cuda()
+    mean, var = synth.normal((C,), 91, 0, 0.2).cuda(), synth.uniform((C,), 92, 0.5, 2.0).cuda()
+    invstd = (var + 1e-5).rsqrt()
+    gamma, beta = synth.uniform((C,), 93, 0.5, 1.5).cuda(), synth.normal((C,), 94, 0, 0.3).cuda()
+    dy = synth.normal((M * C,), 95).cuda()
+    work = torch.empty(lib.bevf_bn_work_floats(C), device=gpu)
+    outs = []
+    for mode in (1, 2):
+        d = dy.clone()
+        dg, db, dx = torch.empty(C, device=gpu), torch.empty(C, device=gpu), torch.empty(M * C, device=gpu)
+        assert lib.bevf_bn_backward_f32(d.data_ptr(), None, x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                                        beta.data_ptr(), work.data_ptr(), dg.data_ptr(), db.data_ptr(), dx.data_ptr(), M, C, C, mode,
+                                        None) == 0
+        outs.append((dg, db, dx, d))
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert torch.equal(a, b)
+    assert torch.equal(outs[1][3], dy) and not torch.equal(outs[0][3], dy)
