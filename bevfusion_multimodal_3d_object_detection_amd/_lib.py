@@ -155,6 +155,7 @@ SIGNATURES = {
     "bevf_bn_apply_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_bn_relu_group_max_idx_f32": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 3 + [C.c_void_p]),
     "bevf_gmax_bn_backward_f32": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 4 + [C.c_void_p]),
+    "bevf_gmax_bn_sums_f32": (C.c_int, [C.c_void_p] * 9 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_bn_backward_f32": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_pool_bn_backward_f32": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_bn_relu_maxpool3x3s2_idx_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_void_p]),

@@ -631,6 +631,20 @@ extern "C" int bevf_pool_bn_backward_f32(const float* dpool, const uint8_t* idx,
   return bevf_check_launch("bevf_pool_bn_backward_f32");
 }
 
+// The first stage of bevf_gmax_bn_backward_f32 alone: dgm [B][C] = dg masked by the ReLU, dbeta = sum dgm, dgamma = sum dgm * xhat
+// (gathered from the B argmax rows per channel).  For callers that never build the dense dx (training.py: the low-rank form of
+// PointNet's last layer).
+extern "C" int bevf_gmax_bn_sums_f32(const float* dg, const float* gmax, const int32_t* idx, const float* x, const float* mean,
+                                     const float* invstd, float* dgm, float* dgamma, float* dbeta, int B, int P, int C, int cs,
+                                     void* stream) {
+  BEVF_REQUIRE(dg && gmax && idx && x && mean && invstd && dgm && dgamma && dbeta, "gmax_bn_sums: null pointer");
+  BEVF_REQUIRE(B > 0 && P > 0 && C > 0 && cs >= C, "gmax_bn_sums: bad shape");
+  BEVF_REQUIRE((long long)B * P < (1ll << 31), "gmax_bn_sums: too many rows");
+  hipLaunchKernelGGL(gmax_bn_sums, dim3((C + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), dg, gmax, idx, x, mean,
+                     invstd, dgm, dbeta, dgamma, B, P, C, cs);
+  return bevf_check_launch("bevf_gmax_bn_sums_f32");
+}
+
 // Backward of y = relu(batchnorm(x)) followed by a max over the P rows of each of B groups (ref src/encoders.py:296-299
 // in training mode): dg [B][C] gradient of the max, gmax its forward value, idx its argmax row.  Writes dgamma, dbeta and
 // the dense dx [B*P][cs]; dgm [B][C] is scratch.  Equivalent to group_max_bwd + bn_backward without the dense dy.

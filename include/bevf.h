@@ -434,6 +434,10 @@ int bevf_bn_relu_group_max_idx_f32(const float* x, const float* mean, const floa
 int bevf_gmax_bn_backward_f32(const float* dg, const float* gmax, const int32_t* idx, const float* x, const float* mean,
                               const float* invstd, const float* gamma, float* dgm, float* dgamma, float* dbeta, float* dx,
                               int B, int P, int C, int cs, void* stream);
+/* Its first stage alone (masked dg, dgamma, dbeta), for callers that never build the dense dx (the low-rank backward of
+ * PointNet's last layer in training.py).                                                                             */
+int bevf_gmax_bn_sums_f32(const float* dg, const float* gmax, const int32_t* idx, const float* x, const float* mean,
+                          const float* invstd, float* dgm, float* dgamma, float* dbeta, int B, int P, int C, int cs, void* stream);
 size_t bevf_linear_bwd_work_floats(int B, int K, int O);
 int bevf_linear_bwd_f32(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, float* work,
                         int B, int K, int O, int perm_inner, int perm_outer, void* stream);

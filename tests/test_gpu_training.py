@@ -587,3 +587,50 @@ def test_bn_backward_without_write_back_is_bit_identical(gpu):
     for a, b in zip(outs[0][:3], outs[1][:3]):
         assert torch.equal(a, b)
     assert torch.equal(outs[1][3], dy) and not torch.equal(outs[0][3], dy)
+
+
+@pytest.mark.parametrize("B,P,K,C", [(3, 700, 64, 96), (2, 1500, 128, 256)])
+def test_lowrank_groupmax_backward_matches_the_dense_path_and_autograd(gpu, B, P, K, C):
+    """PointNet's last layer (Conv1d k=1 -> BatchNorm1d -> ReLU -> max over points, ref src/encoders.py:296-299) in training: the
+    low-rank backward (Gram matrix instead of the dense M x C gradient) against the dense device path and against autograd."""
+    import torch.nn as nn
+    conv, bn = nn.Conv1d(K, C, 1), nn.BatchNorm1d(C)
+    with torch.no_grad():
+        conv.weight.copy_(synth.normal((C, K, 1), 101, 0, (2.0 / K) ** 0.5))
+        conv.bias.copy_(synth.normal((C,), 102, 0, 0.2))
+        bn.weight.copy_(synth.uniform((C,), 103, 0.5, 1.5))
+        bn.bias.copy_(synth.normal((C,), 104, 0, 0.3))
+    a = synth.normal((B * P, K), 105).relu()
+    dg = synth.normal((B, C), 106)
+    # autograd reference (float64)
+    conv64, bn64 = nn.Conv1d(K, C, 1).double(), nn.BatchNorm1d(C).double()
+    conv64.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+    bn64.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    a64 = a.double().view(B, P, K).permute(0, 2, 1).contiguous().requires_grad_(True)
+    y = bn64.train()(conv64(a64)).relu().amax(2)
+    y.backward(dg.double())
+    ref = dict(w=conv64.weight.grad, b=conv64.bias.grad, gamma=bn64.weight.grad, beta=bn64.bias.grad,
+               a=a64.grad.permute(0, 2, 1).reshape(B * P, K))
+    conv, bn = conv.cuda(), bn.cuda().train()
+    outs = {}
+    for lowrank in (False, True):
+        training.LOWRANK_GMAX_BACKWARD = lowrank
+        try:
+            with torch.no_grad():
+                bn.running_mean.zero_(); bn.running_var.fill_(1.0); bn.num_batches_tracked.zero_()
+                lyr = training.ConvBNLayer(conv, bn, True)
+                g, idx = lyr.forward_groupmax(a.view(-1).cuda(), B, P)
+                sink = training.GradSink()
+                da = lyr.backward_from_groupmax(dg.view(-1).cuda().clone(), g, idx, B, P, sink)
+                outs[lowrank] = dict(w=sink.get(conv.weight).clone(), b=sink.get(conv.bias).clone(), gamma=sink.get(bn.weight).clone(),
+                                     beta=sink.get(bn.bias).clone(), a=da[:B * P * K].view(B * P, K).clone())
+        finally:
+            training.LOWRANK_GMAX_BACKWARD = True
+    for k in ref:
+        r = ref[k].reshape(outs[True][k].shape)
+        if k == "b":                                   # a bias in front of a BatchNorm has gradient exactly 0: absolute bound
+            scale = float(ref["beta"].abs().max())
+            assert float(outs[True][k].abs().max()) <= 2e-5 * scale and float(outs[False][k].abs().max()) <= 2e-5 * scale
+            continue
+        assert rel_err(outs[True][k].cpu(), r) <= 2e-5, ("lowrank vs autograd", k)
+        assert rel_err(outs[False][k].cpu(), r) <= 2e-5, ("dense vs autograd", k)
