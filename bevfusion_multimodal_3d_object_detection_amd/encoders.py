@@ -121,8 +121,15 @@ class ResNetCameraEncoder(nn.Module):
         feat, hc, wc = self._eng().run(x.contiguous().float())
         return feat, (B, n, hc, wc)
 
-    @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.training and _training().any_bn_training(self):
+            # a freshly built encoder is in train mode (ref src/encoders.py:805, 829): batch statistics + a gradient path
+            E.require_cuda(x)
+            return _training().camera_encoder_train_forward(self, x)
+        with torch.no_grad():
+            return self._forward_eval(x)
+
+    def _forward_eval(self, x: torch.Tensor) -> torch.Tensor:
         five_d = x.dim() == 5
         feat, (B, n, hc, wc) = self.forward_nhwc(x)
         out = E.to_nchw(feat, B * n, 512, hc, wc)
@@ -130,6 +137,11 @@ class ResNetCameraEncoder(nn.Module):
 
     def get_output_shape(self, input_height: int, input_width: int) -> Tuple[int, int, int]:
         return (self.out_channels, input_height // self.total_stride, input_width // self.total_stride)
+
+
+def _training():
+    from . import training            # train-mode BatchNorm + tape + hand-written backward; imported on first use
+    return training
 
 
 class _PointMLP(nn.Module):
@@ -183,8 +195,14 @@ class PointNetLiDAREncoder(_PointMLP):
             object.__setattr__(self, "_engine", E.PointNetEngine(self))
         return self._engine
 
-    @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.training and _training().any_bn_training(self):
+            E.require_cuda(x)
+            return _training().pointnet_train_forward(self, x)
+        with torch.no_grad():
+            return self._forward_eval(x)
+
+    def _forward_eval(self, x: torch.Tensor) -> torch.Tensor:
         rows = self._rows(x)
         B, N, _ = rows.shape
         g, last = self._eng().run(rows, keep_last=self.return_point_features)
@@ -215,8 +233,14 @@ class RadarEncoder(_PointMLP):
         self._build(self.input_channels, widths, use_bn)
         self._wrap = None
 
-    @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.training and _training().any_bn_training(self):
+            E.require_cuda(x)
+            return _training().radar_train_forward(self, x)
+        with torch.no_grad():
+            return self._forward_eval(x)
+
+    def _forward_eval(self, x: torch.Tensor) -> torch.Tensor:
         if self._wrap is None:
             object.__setattr__(self, "_wrap", _SingleRadar(self))
         return self._wrap(self._rows(x))
@@ -268,8 +292,14 @@ class MultiRadarEncoder(nn.Module):
             object.__setattr__(self, "_engine", E.RadarEngine(self))
         return self._engine
 
-    @torch.no_grad()
     def forward(self, radar_list: List[torch.Tensor]) -> torch.Tensor:
+        if self.training and _training().any_bn_training(self):
+            E.require_cuda(*radar_list)
+            return _training().radar_train_forward(self, list(radar_list))
+        with torch.no_grad():
+            return self._forward_eval(radar_list)
+
+    def _forward_eval(self, radar_list: List[torch.Tensor]) -> torch.Tensor:
         if self.fusion_method not in ("concat", "max", "mean"):
             raise ValueError(f"Unknown fusion method: {self.fusion_method}")
         rows = [self.radar_encoder._rows(r) for r in radar_list]

@@ -6,8 +6,9 @@ conv weights re-laid OIHW -> OHWI, the lidar_init rows left in place and permute
 keeps grow-only device workspaces, and issues the C-ABI calls on torch's current stream.
 Internally every activation is fp32 NHWC; NCHW exists only at the reference's API surface.
 These engines are the eval-mode path (BatchNorm folded from its running statistics).  Training runs through
-training.DetectorTape (train-mode BatchNorm + hand-written backward) for the whole detector; a stand-alone
-encoder / fusion / head module in train mode has no tape of its own and raises (see _check_eval).
+training.DetectorTape (train-mode BatchNorm + hand-written backward): the whole detector, and each camera / PointNet /
+radar encoder, the BEV fusion and the head used on their own, dispatch there from their `forward` while in train mode.
+An engine asked to fold a BatchNorm that is still in train mode (e.g. VFELayer, which has no tape) raises (_check_eval).
 """
 from __future__ import annotations
 
@@ -102,10 +103,11 @@ def _check_eval(module: nn.Module) -> None:
     for m in module.modules():
         if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.training:
             raise L.BevfError(
-                f"{type(module).__name__} is in train mode: stand-alone encoder / fusion / head modules run the "
-                "eval-mode kernels only (BatchNorm folded from running statistics) -- call .eval() first.  Training "
-                "(train-mode BatchNorm, backward, optimiser) is built for the whole detector: "
-                "create_detector(...).train() routes through training.DetectorTape.")
+                f"{type(module).__name__} has a BatchNorm in train mode but was asked for the eval-mode kernels (BatchNorm "
+                "folded from running statistics) -- call .eval() first.  Train-mode BatchNorm, backward and optimiser run "
+                "through training.DetectorTape: the detector, ResNetCameraEncoder, PointNetLiDAREncoder, RadarEncoder / "
+                "MultiRadarEncoder, FlexibleBEVFusion and CenterNetHead reach it from forward() in train mode; VFELayer has "
+                "no train-mode path.")
 
 
 class _Engine:

@@ -98,10 +98,17 @@ class FlexibleBEVFusion(nn.Module):
         """Internal fast path on NHWC camera features (no layout change)."""
         return self._eng().run(cam_nhwc, cam_geom, lidar_features, radar_features)
 
-    @torch.no_grad()
     def forward(self, camera_features: Optional[torch.Tensor] = None, lidar_features: Optional[torch.Tensor] = None,
                 radar_features: Optional[torch.Tensor] = None) -> torch.Tensor:
         E.require_cuda(camera_features, lidar_features, radar_features)
+        if self.training:
+            from . import training
+            if training.any_bn_training(self):          # used outside the detector in train mode: batch statistics + gradients
+                return training.fusion_train_forward(self, camera_features, lidar_features, radar_features)
+        with torch.no_grad():
+            return self._forward_eval(camera_features, lidar_features, radar_features)
+
+    def _forward_eval(self, camera_features, lidar_features, radar_features) -> torch.Tensor:
         cam_nhwc = cam_geom = None
         if self.use_camera and camera_features is not None:
             x = camera_features.float()
@@ -205,11 +212,19 @@ class CenterNetHead(nn.Module):
     def forward_nhwc(self, bev_nhwc: torch.Tensor, B: int, H: int, W: int) -> Dict[str, torch.Tensor]:
         return self._eng().run(bev_nhwc, B, H, W)
 
-    @torch.no_grad()
     def forward(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
         E.require_cuda(x)
-        B, _, H, W = x.shape
-        return self.forward_nhwc(E.to_nhwc(x.float()).to(self._eng().dtype), B, H, W)
+        if self.training and torch.is_grad_enabled() and self._eng().dtype == torch.float32 \
+                and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from . import training                      # no BatchNorm in the head: same values as eval mode, plus a gradient path
+            return training.head_train_forward(self, x)
+        with torch.no_grad():
+            B, _, H, W = x.shape
+            return self.forward_nhwc(E.to_nhwc(x.float()).to(self._eng().dtype), B, H, W)
+
+
+def _any_bn_training(module: nn.Module) -> bool:
+    return any(isinstance(m, nn.modules.batchnorm._BatchNorm) and m.training for m in module.modules())
 
 
 class FlexibleMultiModal3DDetector(nn.Module):
@@ -268,7 +283,8 @@ class FlexibleMultiModal3DDetector(nn.Module):
 
     def forward(self, camera_imgs: Optional[torch.Tensor] = None, lidar_points: Optional[torch.Tensor] = None,
                 radar_points: Optional[List[torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
-        if self.training and torch.is_grad_enabled():
+        if self.training and (torch.is_grad_enabled() or _any_bn_training(self)):
+            # under no_grad a train-mode model still normalises with batch statistics and updates the running buffers, as torch does
             from . import training                      # train-mode BN + tape + hand-written backward (training.py)
             E.require_cuda(camera_imgs, lidar_points)
             return training.detector_train_forward(self, camera_imgs, lidar_points, radar_points)
@@ -280,9 +296,9 @@ class FlexibleMultiModal3DDetector(nn.Module):
         if self.use_camera and camera_imgs is not None:
             cam, geom = self.camera_encoder.forward_nhwc(camera_imgs)       # stays NHWC: no layout change
         if self.use_lidar and lidar_points is not None:
-            lid = self.lidar_encoder(lidar_points)
+            lid = self.lidar_encoder._forward_eval(lidar_points)
         if self.use_radar and radar_points is not None:
-            rad = self.radar_encoder(radar_points)
+            rad = self.radar_encoder._forward_eval(radar_points)
         fused, B = self.fusion.forward_nhwc(cam, geom, lid, rad)
         return self.det_head.forward_nhwc(fused, B, self.fusion.bev_h, self.fusion.bev_w)
 

@@ -11,6 +11,7 @@ allocation and for weight layout permutes; no torch compute op touches an activa
 from __future__ import annotations
 
 import ctypes as C
+from types import SimpleNamespace
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -900,14 +901,29 @@ class DetectorTape:
         if self.has_lid:
             lid_feat = self._lidar_forward(pts)
             B = self.pn_geom[0]
+        fused = self._fusion_forward(cam_feat, (B, ncam, Hc, Wc) if self.has_cam else None, lid_feat, rad_feat, B, dev)
+        return self._head_forward(fused, B, Sh, Sw)
+
+    def _fusion_forward(self, cam_feat, cam_geom, lid_feat, rad_feat, B, dev):
+        """FlexibleBEVFusion under train-mode BatchNorm (ref src/fusion.py:209-297): NHWC camera features [B*ncam*Hc*Wc*C] with
+        cam_geom = (B, ncam, Hc, Wc), LiDAR (B, C_l) and radar (B, C_r) vectors -> fused NHWC map [B*Sh*Sw*bev_channels]."""
+        fus = self.m.fusion
+        Sh, Sw, bc = fus.bev_h, fus.bev_w, fus.bev_channels
+        P = Sh * Sw
+        self.has_cam, self.has_lid, self.has_rad = cam_feat is not None, lid_feat is not None, rad_feat is not None
+        nmod = int(self.has_cam) + int(self.has_lid) + int(self.has_rad)
+        if nmod == 0:
+            raise ValueError("No modality features provided")
         ccs = bc * nmod
         if ccs != fus.bev_fusion[0].weight.shape[1]:
             raise RuntimeError(f"expected input to have {fus.bev_fusion[0].weight.shape[1]} channels, but got {ccs} channels instead")
         concat = _new(B * P * ccs, dev)
         slot = 0
         self.B, self.ccs = B, ccs
+        self.S = (Sh, Sw)
         if self.has_cam:
-            Cc = 512
+            _, ncam, Hc, Wc = cam_geom
+            Cc = fus.camera_proj[0].weight.shape[1]
             self.cam_pool_geom = (B, ncam, Hc * Wc, Cc)
             pooled = cam_feat
             if ncam > 1:
@@ -963,8 +979,15 @@ class DetectorTape:
         self.f2 = ConvBNLayer(fus.bev_fusion[3], fus.bev_fusion[4], True)
         a1, _, _ = self.f1.forward(concat, B, Sh, Sw)
         fused, _, _ = self.f2.forward(a1, B, Sh, Sw)
-        # head: the five 3x3 branches as one conv (weights concatenated along Cout), then the tail kernel
-        head = m.det_head
+        return fused
+
+    def _head_forward(self, fused, B, Sh, Sw):
+        """CenterNetHead (ref src/fusion.py:869-884): the five 3x3 branches as one conv (weights concatenated along Cout), then
+        the tail kernel."""
+        head = self.m.det_head
+        dev = fused.device
+        P = Sh * Sw
+        self.B = B
         convs3 = [getattr(head, f"{n}_head")[0] for n in E.HEAD_BRANCHES]
         convs1 = [getattr(head, f"{n}_head")[2] for n in E.HEAD_BRANCHES]
         self.hc = convs3[0].weight.shape[0]
@@ -984,8 +1007,21 @@ class DetectorTape:
         return outs
 
     def backward(self, douts: List[torch.Tensor], reducer=None) -> GradSink:
-        m = self.m
         sink = GradSink(reducer)
+        dfused, pre_f2 = self._head_backward(douts, sink, self.f2)
+
+        def camera(dfeat):
+            sink.ready()              # head, fusion, radar, LiDAR (the 164 MB dense layer): reduce under the camera trunk
+            self._camera_backward(dfeat, sink)
+
+        self._fusion_backward(dfused, pre_f2, sink, on_radar=lambda d: self._radar_backward(d, sink),
+                              on_lidar=lambda d: self._lidar_backward(d, sink), on_camera=camera)
+        sink.finish()
+        return sink
+
+    def _head_backward(self, douts: List[torch.Tensor], sink: GradSink, f2=None):
+        """-> (gradient of the fused NHWC map, BatchNorm-backward partials for `f2` or None)."""
+        m = self.m
         B, (Sh, Sw) = self.B, self.S
         P = Sh * Sw
         dev = self.outs[0].device
@@ -1022,10 +1058,20 @@ class DetectorTape:
             sink.add(c3.weight, dw3[k * self.hc:(k + 1) * self.hc])
             sink.add(c3.bias, db3[k * self.hc:(k + 1) * self.hc])
         pre_f2 = None
-        if FUSE_BN_BACKWARD and self.f2.can_take_fused_dy() and dgrad_can_fuse_bn(B, Sh, Sw, cin, c5, 3, 1, 1):
-            dfused, pre_f2 = conv_dgrad(dhid, self.head_w3, B, Sh, Sw, cin, c5, 3, 1, 1, bnb=self.f2.bnb_request())
+        if FUSE_BN_BACKWARD and f2 is not None and f2.can_take_fused_dy() and dgrad_can_fuse_bn(B, Sh, Sw, cin, c5, 3, 1, 1):
+            dfused, pre_f2 = conv_dgrad(dhid, self.head_w3, B, Sh, Sw, cin, c5, 3, 1, 1, bnb=f2.bnb_request())
         else:
             dfused = conv_dgrad(dhid, self.head_w3, B, Sh, Sw, cin, c5, 3, 1, 1)
+        return dfused, pre_f2
+
+    def _fusion_backward(self, dfused, pre_f2, sink: GradSink, on_radar=None, on_lidar=None, on_camera=None):
+        """Backward of `_fusion_forward`.  Each modality's input gradient (radar (B*C_r), LiDAR (B*C_l), camera NHWC) goes to its
+        callback as soon as it exists -- the detector continues into that encoder there -- and is returned as well."""
+        m = self.m
+        B, (Sh, Sw) = self.B, self.S
+        P = Sh * Sw
+        dev = dfused.device
+        drad = dlid = dfeat = None
         da1, _, pre_f1 = self.f2.backward(dfused, sink, fuse_next=self.f1, pre=pre_f2)
         dconcat, _ = self.f1.backward(da1, sink, pre=pre_f1)
         bc = m.fusion.bev_channels
@@ -1036,7 +1082,8 @@ class DetectorTape:
             dr0, _ = self.rr1.backward(dr1, sink)
             drv = torch.cat([colsum(dr0[b * P * bc:], P, bc) for b in range(B)])      # d(broadcast) = sum over cells
             drad = self.rp.backward(drv.contiguous(), sink)
-            self._radar_backward(drad, sink)
+            if on_radar is not None:
+                on_radar(drad)
         if self.has_lid:
             dg3 = self.lid_resize.backward(dconcat[self.lid_slot * bc:])
             dg2, _ = self.lu2.backward(dg3, sink)
@@ -1044,7 +1091,8 @@ class DetectorTape:
             dgrid0, _ = self.lu1.backward(dg1, sink)
             dhid_l = self.li2.backward(dgrid0, sink)
             dlid = self.li0.backward(dhid_l, sink)
-            self._lidar_backward(dlid, sink)
+            if on_lidar is not None:
+                on_lidar(dlid)
         if self.has_cam:
             dt2 = self.cam_resize.backward(dconcat[self.cam_slot * bc:])
             dt1, _ = self.cp2.backward(dt2, sink)
@@ -1055,10 +1103,9 @@ class DetectorTape:
                 dfeat = _new(Bc * ncam * Pc * Cc, dev)
                 _ck(_lib().bevf_cam_mean_bwd_f32(dpooled.data_ptr(), dfeat.data_ptr(), Bc, ncam, Pc, Cc, _st()),
                     "bevf_cam_mean_bwd_f32")
-            sink.ready()              # head, fusion, radar, LiDAR (the 164 MB dense layer): reduce under the camera trunk
-            self._camera_backward(dfeat, sink)
-        sink.finish()
-        return sink
+            if on_camera is not None:
+                on_camera(dfeat)
+        return drad, dlid, dfeat
 
 
 _GRAD_REDUCER = None
@@ -1095,27 +1142,217 @@ class _DetectorTrainFn(torch.autograd.Function):
             finally:
                 _ZPOOL = None
         ctx.tape = None                                   # activations are dead now: hand them back to the allocator
-        grads = []
-        for p in ctx.params:
-            g = sink.get(p)
-            if g is not None:
-                g = g.reshape(p.shape).contiguous()
-                if g.untyped_storage().data_ptr() == pool.buf.untyped_storage().data_ptr():
-                    g = g.clone()                             # never hand out a view of the shared zero pool
-            grads.append(g)
-        return (None, None, None, None, *grads)
+        return (None, None, None, None, *_param_grads(sink, ctx.params, pool))
 
 
-def detector_train_forward(model, imgs, pts, radars) -> Dict[str, torch.Tensor]:
+def _owned(g, pool):
+    """Never hand out a view of the shared zero pool."""
+    if g is not None and g.untyped_storage().data_ptr() == pool.buf.untyped_storage().data_ptr():
+        return g.clone()
+    return g
+
+
+def _param_grads(sink: GradSink, params, pool) -> list:
+    grads = []
+    for p in params:
+        g = sink.get(p)
+        if g is not None:
+            g = _owned(g.reshape(p.shape).contiguous(), pool)
+        grads.append(g)
+    return grads
+
+
+def any_bn_training(module: nn.Module) -> bool:
+    return any(isinstance(m, nn.modules.batchnorm._BatchNorm) and m.training for m in module.modules())
+
+
+def _require_all_bn_training(model: nn.Module) -> None:
     for name, mod in model.named_modules():
         if isinstance(mod, nn.modules.batchnorm._BatchNorm) and not mod.training:
             # e.g. _freeze_bn() called AFTER model.train(); the reference's own order (freeze in the constructor, then
             # model.train() in train_one_epoch, ref src/encoders.py:122-131 + src/train_detect.py:394) leaves every
             # BatchNorm in train mode with frozen affine parameters, which is what the tape implements
-            raise L.BevfError(f"training: BatchNorm '{name}' is in eval mode inside a detector in train mode; the training "
+            raise L.BevfError(f"training: BatchNorm '{name}' is in eval mode inside a module in train mode; the training "
                               "tape normalises with batch statistics throughout (mixed-mode BatchNorm is not built)")
+
+
+def detector_train_forward(model, imgs, pts, radars) -> Dict[str, torch.Tensor]:
+    _require_all_bn_training(model)
     params = [p for p in model.parameters() if p.requires_grad]
     outs = _DetectorTrainFn.apply(model, imgs, pts, radars, *params)
+    return dict(zip(E.HEAD_BRANCHES, outs))
+
+
+# ---- stand-alone modules under train-mode BatchNorm (ref src/encoders.py:792-846 calls freshly built encoders, i.e. in train mode) ----
+
+class _ModuleTrainFn(torch.autograd.Function):
+    """One encoder / fusion / head module used outside the detector: the matching part of DetectorTape.
+    `run_fwd()` -> (tape, outputs); `run_bwd(tape, douts, sink)` -> one gradient per tensor input (None where there is none)."""
+
+    @staticmethod
+    def forward(ctx, run_fwd, run_bwd, n_in, *tensors):
+        with torch.no_grad():
+            tape, outs = run_fwd()
+        ctx.tape, ctx.run_bwd, ctx.n_in, ctx.params = tape, run_bwd, n_in, tensors[n_in:]
+        return tuple(o.detach() for o in outs)                    # fresh aliases: see _DetectorTrainFn.forward
+
+    @staticmethod
+    def backward(ctx, *douts):
+        if ctx.tape is None:
+            raise RuntimeError("Trying to backward through the module a second time: its saved activations were freed")
+        global _ZPOOL
+        with torch.no_grad():
+            pool = _ZPOOL = _ZeroPool(next(g for g in douts if g is not None).device)
+            try:
+                sink = GradSink(None)
+                dins = ctx.run_bwd(ctx.tape, list(douts), sink)
+                sink.finish()
+            finally:
+                _ZPOOL = None
+        ctx.tape = None
+        need = ctx.needs_input_grad[3:3 + ctx.n_in]
+        dins = [_owned(d, pool) if (n and d is not None) else None for d, n in zip(dins, need)]
+        return (None, None, None, *dins, *_param_grads(sink, ctx.params, pool))
+
+
+def _no_input_grad(x, what: str) -> None:
+    if isinstance(x, torch.Tensor) and x.requires_grad:
+        raise L.BevfError(f"training: {what} has no gradient path on the device (the reference's training loop never asks for "
+                          "one, ref src/train_detect.py:401-434); detach the input")
+
+
+def _nhwc(x: torch.Tensor) -> torch.Tensor:
+    """(N,C,H,W) -> flat NHWC fp32 buffer."""
+    return E.to_nhwc(x.float().contiguous()).float().reshape(-1)
+
+
+def camera_encoder_train_forward(enc, x: torch.Tensor) -> torch.Tensor:
+    """ResNetCameraEncoder.forward under train-mode BatchNorm (ref src/encoders.py:133-172): batch statistics, running buffers
+    updated, gradients for every trainable parameter."""
+    _require_all_bn_training(enc)
+    _no_input_grad(x, "the camera images")
+    five_d = x.dim() == 5
+    geom = {}
+
+    def fwd():
+        tape = DetectorTape(SimpleNamespace(camera_encoder=enc))
+        feat, (B, n, h, w) = tape._camera_forward(x)
+        geom["g"] = (B, n, h, w)
+        return tape, (E.to_nchw(feat, B * n, tape.proj.cout, h, w),)
+
+    def bwd(tape, douts, sink):
+        B, n, h, w = geom["g"]
+        tape._camera_backward(_nhwc(douts[0].reshape(B * n, tape.proj.cout, h, w)), sink)
+        return [None]
+
+    (out,) = _ModuleTrainFn.apply(fwd, bwd, 1, x, *[p for p in enc.parameters() if p.requires_grad])
+    B, n, h, w = geom["g"]
+    return out.view(B, n, out.shape[1], h, w) if five_d else out
+
+
+def pointnet_train_forward(enc, x: torch.Tensor) -> torch.Tensor:
+    """PointNetLiDAREncoder.forward under train-mode BatchNorm (ref src/encoders.py:271-306) -> (B, feat_dim)."""
+    _require_all_bn_training(enc)
+    _no_input_grad(x, "the LiDAR points")
+    if getattr(enc, "return_point_features", False):
+        raise L.BevfError("training: PointNetLiDAREncoder(return_point_features=True) has no train-mode path on the device "
+                          "(the detector uses the global feature, ref src/fusion.py:1105-1108); call .eval() for per-point features")
+
+    def fwd():
+        tape = DetectorTape(SimpleNamespace(lidar_encoder=enc))
+        g = tape._lidar_forward(x)
+        B, feat = tape.pn_geom[0], tape.pn_layers[-1].cout
+        return tape, (g.reshape(-1)[:B * feat].view(B, feat),)
+
+    def bwd(tape, douts, sink):
+        tape._lidar_backward(douts[0].contiguous().float().reshape(-1), sink)
+        return [None]
+
+    (out,) = _ModuleTrainFn.apply(fwd, bwd, 1, x, *[p for p in enc.parameters() if p.requires_grad])
+    return out
+
+
+def radar_train_forward(enc, radar_list) -> torch.Tensor:
+    """MultiRadarEncoder.forward (ref src/encoders.py:619-661), or one RadarEncoder (ref :527-557, `radar_list` a single tensor),
+    under train-mode BatchNorm -> (B, feat_dim)."""
+    _require_all_bn_training(enc)
+    single = isinstance(radar_list, torch.Tensor)
+    sweeps = [radar_list] if single else list(radar_list)
+    for r in sweeps:
+        _no_input_grad(r, "the radar points")
+    # one encoder alone = the shared encoder over one sweep, "max" over that single sweep being the identity
+    renc = SimpleNamespace(radar_encoder=enc, fusion_method="max") if single else enc
+
+    def fwd():
+        tape = DetectorTape(SimpleNamespace(radar_encoder=renc))
+        out, B = tape._radar_forward(sweeps)
+        feat = tape.rad_geom[2] if renc.fusion_method != "concat" else renc.fusion_fc.weight.shape[0]
+        return tape, (out.reshape(-1)[:B * feat].view(B, feat),)
+
+    def bwd(tape, douts, sink):
+        tape._radar_backward(douts[0].contiguous().float().reshape(-1), sink)
+        return [None] * len(sweeps)
+
+    (out,) = _ModuleTrainFn.apply(fwd, bwd, len(sweeps), *sweeps, *[p for p in enc.parameters() if p.requires_grad])
+    return out
+
+
+def fusion_train_forward(fus, camera_features=None, lidar_features=None, radar_features=None) -> torch.Tensor:
+    """FlexibleBEVFusion.forward under train-mode BatchNorm (ref src/fusion.py:209-297) -> (B, bev_channels, bev_h, bev_w), with
+    gradients for the parameters AND for the three feature inputs."""
+    _require_all_bn_training(fus)
+    cam = camera_features if fus.use_camera else None
+    lid = lidar_features if fus.use_lidar else None
+    rad = radar_features if fus.use_radar else None
+    first = next((t for t in (cam, lid, rad) if t is not None), None)
+    if first is None:
+        raise ValueError("No modality features provided")
+    B, dev = first.shape[0], first.device
+    geom = None
+    if cam is not None:
+        geom = (B, cam.shape[1], cam.shape[3], cam.shape[4]) if cam.dim() == 5 else (B, 1, cam.shape[2], cam.shape[3])
+
+    def fwd():
+        tape = DetectorTape(SimpleNamespace(fusion=fus))
+        cam_nhwc = None
+        if cam is not None:
+            _, n, h, w = geom
+            cam_nhwc = _nhwc(cam.detach().reshape(B * n, -1, h, w))
+        fused = tape._fusion_forward(cam_nhwc, geom, None if lid is None else lid.detach().float().contiguous(),
+                                     None if rad is None else rad.detach().float().contiguous(), B, dev)
+        return tape, (E.to_nchw(fused, B, fus.bev_channels, fus.bev_h, fus.bev_w),)
+
+    def bwd(tape, douts, sink):
+        drad, dlid, dcam = tape._fusion_backward(_nhwc(douts[0]), None, sink)
+        if dcam is not None:
+            _, n, h, w = geom
+            Cc = tape.cam_pool_geom[3]
+            dcam = E.to_nchw(dcam, B * n, Cc, h, w).view(cam.shape)
+        if dlid is not None:
+            dlid = dlid.reshape(-1)[:lid.numel()].view(lid.shape)
+        if drad is not None:
+            drad = drad.reshape(-1)[:rad.numel()].view(rad.shape)
+        return [dcam, dlid, drad]
+
+    (out,) = _ModuleTrainFn.apply(fwd, bwd, 3, cam, lid, rad, *[p for p in fus.parameters() if p.requires_grad])
+    return out
+
+
+def head_train_forward(head, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """CenterNetHead.forward with a gradient path (ref src/fusion.py:869-884; the head has no BatchNorm, so train and eval mode
+    compute the same values): gradients for its parameters and for the BEV map `x` (B, C, H, W)."""
+    B, _, Sh, Sw = x.shape
+
+    def fwd():
+        tape = DetectorTape(SimpleNamespace(det_head=head))
+        tape.S = (Sh, Sw)
+        return tape, tuple(tape._head_forward(_nhwc(x.detach()), B, Sh, Sw))
+
+    def bwd(tape, douts, sink):
+        dfused, _ = tape._head_backward(douts, sink, None)
+        return [E.to_nchw(dfused, B, x.shape[1], Sh, Sw)]
+
+    outs = _ModuleTrainFn.apply(fwd, bwd, 1, x, *[p for p in head.parameters() if p.requires_grad])
     return dict(zip(E.HEAD_BRANCHES, outs))
 
 

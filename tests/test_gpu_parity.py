@@ -291,10 +291,15 @@ def test_lidar_resize_extension_128(gpu):
         assert rel_err(out[k].cpu(), ref[k]) <= MTOL, k
 
 
-def test_standalone_modules_refuse_train_mode(gpu):
-    """Train-mode BatchNorm is built for the detector (training.py); a stand-alone encoder still needs eval()."""
-    m = encoders.ResNetCameraEncoder(backbone="resnet18", pretrained=False).cuda().train()
+def test_modules_without_a_train_mode_path_refuse_it(gpu):
+    """Train-mode BatchNorm runs through training.DetectorTape for the detector and its five module kinds
+    (tests/test_gpu_standalone_train.py); VFELayer has no tape, and mixed-mode BatchNorm is not built: both refuse loudly."""
+    v = encoders.VFELayer(4, 32).cuda().train()
     with pytest.raises(RuntimeError, match="call .eval\\(\\) first"):
+        v(torch.zeros(1, 3, 5, 4, device=gpu))
+    m = encoders.ResNetCameraEncoder(backbone="resnet18", pretrained=False).cuda().train()
+    m.layer2[0].bn1.eval()
+    with pytest.raises(RuntimeError, match="mixed-mode BatchNorm"):
         m(torch.zeros(1, 3, 32, 32, device=gpu))
 
 

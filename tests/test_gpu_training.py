@@ -445,7 +445,7 @@ def test_freeze_bn_under_model_train(gpu):
     assert not torch.equal(before, model.camera_encoder.layer2[0].bn1.running_mean)
     # freezing AFTER model.train() leaves eval-mode BatchNorms inside a training detector: refused, not silently wrong
     model.camera_encoder._freeze_bn()
-    with pytest.raises(Exception, match="eval mode inside a detector in train mode"):
+    with pytest.raises(Exception, match="eval mode inside a module in train mode"):
         model(imgs.cuda(), pts.cuda(), None)
 
 
