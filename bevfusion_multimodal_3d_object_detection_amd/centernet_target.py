@@ -173,3 +173,31 @@ class DetectionLoss(nn.Module):
         super().__init__()
         raise NotImplementedError("DetectionLoss (ref src/centernet_target.py:13-116) belongs to the MLP detection "
                                   "head, which is outside the MI355X bev+centernet hot path; use CenterNetLoss")
+
+
+def example_usage(seed: int = 0) -> Dict[str, torch.Tensor]:
+    """ref :626-679 -- the reference's own walk-through of this module: targets for its two hand-written frames (2 + 3 boxes) on
+    a 200 x 200 BEV grid, then CenterNetLoss on random predictions; prints the target shapes and the five loss terms and returns
+    the loss dict.  Runs on the GPU only (the predictions come from torch's generator, seeded here)."""
+    if not torch.cuda.is_available():
+        raise L.BevfError("example_usage runs the target / loss kernels on the GPU: no 'cuda' device is visible")
+    device = torch.device("cuda")
+    batch = {
+        "gt_boxes": [torch.tensor([[10.5, 20.3, -0.5, 1.8, 4.5, 1.6, 0.5], [-5.2, -15.7, -0.8, 2.0, 4.8, 1.7, -1.2]]),
+                     torch.tensor([[8.1, 12.4, -0.6, 1.9, 4.6, 1.65, 0.8], [15.3, -8.9, -0.7, 1.85, 4.55, 1.62, -0.5],
+                                   [-12.7, 25.6, -0.55, 1.95, 4.7, 1.68, 1.1]])],
+        "gt_labels": [torch.tensor([0, 0]), torch.tensor([0, 1, 0])],
+    }
+    targets = prepare_centernet_targets(batch=batch, device=device, pc_range=[-51.2, -51.2, -5.0, 51.2, 51.2, 3.0],
+                                        bev_size=(200, 200), num_classes=10)
+    print("Target shapes:")
+    for key, value in targets.items():
+        print(f"  {key}: {value.shape}")
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    predictions = {k: torch.randn(2, c, 200, 200, generator=gen).to(device)
+                   for k, c in (("heatmap", 10), ("offset", 2), ("size", 3), ("rot", 2), ("vel", 2))}
+    losses = CenterNetLoss()(predictions, targets)
+    print("\nLosses:")
+    for key, value in losses.items():
+        print(f"  {key}: {value.item():.4f}")
+    return losses

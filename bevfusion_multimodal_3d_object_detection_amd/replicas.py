@@ -3,6 +3,7 @@ collective.  torch.distributed (RCCL on ROCm, gloo in the CPU tes
 line the ranks up and to take the MAX over ranks of the elapsed time."""
 from __future__ import annotations
 
+import datetime
 import os
 from typing import List, Optional, Tuple
 
@@ -22,6 +23,9 @@ def init(backend: str, device: Optional[torch.device] = None):
     import torch.distributed as dist
     if not dist.is_initialized():
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        # a collective that never completes (a rank died, mismatched calls) aborts the job after this long instead of
+        # holding N GPUs for torch's default 10 minutes
+        kw["timeout"] = datetime.timedelta(seconds=int(os.environ.get("BEVF_DIST_TIMEOUT_S", "300")))
         dist.init_process_group(backend, **kw)
     return dist
 

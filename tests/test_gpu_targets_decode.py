@@ -101,3 +101,20 @@ def test_decode_true_labels_and_topk_helpers(gpu):
     s1, i1 = torch.topk(ref.view(ref.shape[0], ref.shape[1], -1), 20, dim=2)
     assert torch.equal(s1.view(ref.shape[0], -1).gather(1, ind.cpu()), sc.cpu())
     assert torch.equal(ref[torch.arange(ref.shape[0])[:, None], ind.cpu() // 20, ys.cpu(), xs.cpu()], sc.cpu())
+
+
+def test_example_usage_walkthrough(gpu, capsys):
+    """ref src/centernet_target.py:626-679: the module's own walk-through (two hand-written frames on a 200 x 200 grid, random
+    predictions) prints the 12 target shapes and the loss terms; the values equal the oracle's on the same predictions."""
+    losses = ct.example_usage(seed=3)
+    text = capsys.readouterr().out
+    assert "Target shapes:" in text and "heatmap: torch.Size([2, 10, 200, 200])" in text and "ind: torch.Size([2, 500])" in text
+    assert "Losses:" in text and "total_loss:" in text
+    boxes, labels = cases.target_inputs(dict(kind="hand"))
+    tgt = ref_targets.make_targets(boxes, labels, bev_size=(200, 200))
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    pred = {k: torch.randn(2, c, 200, 200, generator=gen) for k, c in (("heatmap", 10), ("offset", 2), ("size", 3), ("rot", 2),
+                                                                         ("vel", 2))}
+    ref = ref_targets.centernet_loss(pred, tgt)
+    for k, v in ref.items():
+        assert abs(float(losses[k]) - float(v)) <= 2e-5 * max(abs(float(v)), 1e-3), k
