@@ -92,6 +92,8 @@ SIGNATURES = {
     "bevf_stem_conv7x7_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_maxpool3x3s2_nhwc_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_pointwise_smallk_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
+    "bevf_pointnet_front_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 11),
+    "bevf_pointnet_front_pack_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 2 + [C.c_void_p]),
     "bevf_group_max_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 3 + [C.c_void_p]),
     "bevf_radar_mlp_max_f32": (C.c_int, [C.POINTER(RadarDesc), C.c_void_p]),
     "bevf_linear_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p]),
@@ -371,6 +373,23 @@ def pointwise_smallk(x, w, scale, shift, y, M: int, K: int, Cout: int, relu: boo
         raise BevfError("pointwise: buffer sizes do not match M,K,Cout")
     fn = "bevf_pointwise_smallk_f32" if y.dtype == torch.float32 else "bevf_pointwise_smallk_bf16out"
     _check(getattr(lib(), fn)(_pc(x), _pc(w), _pc(scale), _pc(shift), _p(y, y.dtype), M, K, Cout, int(relu), _stream()), fn)
+
+
+def pointnet_front_pack(w: torch.Tensor) -> torch.Tensor:
+    """(Cout, Cin) fp32 pointwise filter -> MFMA fragment order for pointnet_front."""
+    cout, cin = w.shape
+    w = w.detach().float().contiguous()
+    wf = torch.empty(cout * cin, device=w.device)
+    _check(lib().bevf_pointnet_front_pack_f32(_p(w), _p(wf), cout, cin, _stream()), "bevf_pointnet_front_pack_f32")
+    return wf
+
+
+def pointnet_front(x, w1, s1, b1, w2f, s2, b2, w3f, s3, b3, y, M: int, K: int):
+    if x.numel() < M * K or w1.numel() != 64 * K or w2f.numel() != 128 * 64 or w3f.numel() != 256 * 128 or y.numel() < M * 256 \
+            or min(s1.numel(), b1.numel()) < 64 or min(s2.numel(), b2.numel()) < 128 or min(s3.numel(), b3.numel()) < 256:
+        raise BevfError("pointnet_front: buffer sizes do not match M, K and the 64/128/256 widths")
+    _check(lib().bevf_pointnet_front_f32(_pc(x), M, K, _pc(w1), _pc(s1), _pc(b1), _pc(w2f), _pc(s2), _pc(b2), _pc(w3f), _pc(s3),
+                                         _pc(b3), _p(y), _stream()), "bevf_pointnet_front_f32")
 
 
 def group_max(x, y, G: int, P: int, Cc: int):

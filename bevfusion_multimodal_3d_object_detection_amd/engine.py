@@ -310,6 +310,9 @@ class CameraEncoderEngine(_Engine):
 
 # ---- shared per-point MLP + max (ref src/encoders.py:271-306) -------------------------------------------
 
+FUSE_POINTNET_FRONT = True   # inference, fp32: conv1 -> conv2 -> conv3 as one kernel, activations in registers (csrc/pointnet_front.hip)
+
+
 class PointNetEngine(_Engine):
     def pack(self) -> None:
         m = self.module
@@ -321,6 +324,11 @@ class PointNetEngine(_Engine):
         self.s0, self.b0 = _bn_fold(convs[0].bias, bns[0], w0.shape[0], w0.device)
         self.c0 = w0.shape[0]
         self.layers = [pack_conv(c, b, True) for c, b in zip(convs[1:], bns[1:])]   # the last layer fuses the max over points (colmax)
+        # fused front (exact fp32 modes, the reference's 64 / 128 / 256 widths): conv2 / conv3 filters in MFMA fragment order
+        self.front = None
+        if (FUSE_POINTNET_FRONT and self.dtype == torch.float32 and _CONV_MODE in ("f32", "wino") and self.cin <= 8
+                and len(convs) >= 4 and [c.weight.shape[0] for c in convs[:3]] == [64, 128, 256]):
+            self.front = [L.pointnet_front_pack(c.weight.detach().reshape(c.weight.shape[0], -1)) for c in convs[1:3]]
 
     def run(self, pts: torch.Tensor, keep_last: bool = False):
         """pts: (B,N,C) contiguous -> (B, feat) global max feature [and the (B*N, feat) last activations].
@@ -344,9 +352,18 @@ class PointNetEngine(_Engine):
     def _run_frames(self, pts: torch.Tensor, gmax: torch.Tensor, keep_last: bool):
         B, N, Cc = pts.shape
         M = B * N
-        a = self.buf("l0", M * self.c0)
-        L.pointwise_smallk(pts.float(), self.w0, self.s0, self.b0, a, M, Cc, self.c0, True)
-        for i, pc in enumerate(self.layers[:-1]):
+        if self.front is not None:
+            l2, l3 = self.layers[0], self.layers[1]
+            a = self.buf("l2", M * l3.cout)
+            with _span("conv_igemm_f32", flops=2.0 * M * (l2.cin * l2.cout + l3.cin * l3.cout)):     # the two MFMA layers
+                L.pointnet_front(pts.float(), self.w0, self.s0, self.b0, self.front[0], l2.scale, l2.shift, self.front[1],
+                                 l3.scale, l3.shift, a, M, Cc)
+            rest = list(enumerate(self.layers[:-1]))[2:]
+        else:
+            a = self.buf("l0", M * self.c0)
+            L.pointwise_smallk(pts.float(), self.w0, self.s0, self.b0, a, M, Cc, self.c0, True)
+            rest = list(enumerate(self.layers[:-1]))
+        for i, pc in rest:
             o = self.buf(f"l{i + 1}", M * pc.cout)
             _run_conv(pc, a, o, M, 1, 1)
             a = o

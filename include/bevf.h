@@ -119,6 +119,16 @@ int bevf_maxpool3x3s2_nhwc_f32(const float* x, float* y, int N, int H, int W, in
 int bevf_pointwise_smallk_f32(const float* x, const float* w, const float* scale, const float* shift,
                               float* y, int M, int K, int Cout, int relu, void* stream);
 
+/* PointNet conv1 -> conv2 -> conv3 (K -> 64 -> 128 -> 256, each with folded BatchNorm + ReLU; ref src/encoders.py:289-291:
+ * `x = F.relu(self.bn1(self.conv1(x)))` ... `bn3(conv3(x))`) as ONE launch whose 64- and 128-wide activations stay in
+ * registers.  x: [M][K] points (K <= 8), w1: [64][K], w2f / w3f: the [128][64] and [256][128] filters in MFMA fragment
+ * order (bevf_pointnet_front_pack_f32), s* / b*: per-channel scale / shift, y: [M][256].                              */
+int bevf_pointnet_front_f32(const float* x, int M, int K, const float* w1, const float* s1, const float* b1,
+                            const float* w2f, const float* s2, const float* b2, const float* w3f, const float* s3,
+                            const float* b3, float* y, void* stream);
+/* w: [Cout][Cin] row-major (Conv1d k=1 weight) -> wf: [Cout/32][Cin/32][4][64][4] fragments for the kernel above.     */
+int bevf_pointnet_front_pack_f32(const float* w, float* wf, int Cout, int Cin, void* stream);
+
 /* y[g][c] = max over the P rows of group g: the per-voxel max of VFELayer ("pillar reduction"),
  * ref src/encoders.py:451-452.  x: [G][P][C] post-ReLU point features -> y: [G][C].           */
 int bevf_group_max_f32(const float* x, float* y, int G, int P, int C, void* stream);
