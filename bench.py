@@ -436,6 +436,16 @@ def main():
     # leg's record then goes to stderr (`[bench extra] {...}`).  N = 1: no collective anywhere, one line at the end with everything.
     if world > 1:
         emit([])
+        # The headline is out; from here on nothing may change this job's exit status.  A collective of the extra leg that never
+        # completes would end in RCCL's watchdog aborting the rank (non-zero exit) after the process-group timeout: leave first.
+        import threading
+
+        def _deadline():
+            print("[bench extra] deadline reached, leaving with the headline already printed", file=sys.stderr, flush=True)
+            os._exit(0)
+        guard = threading.Timer(float(os.environ.get("BEVF_EXTRA_DEADLINE_S", "240")), _deadline)
+        guard.daemon = True
+        guard.start()
     extras = []
     for config, dtype, mode, batch, *conv_override in plan:
         if mode == "train":
@@ -452,8 +462,11 @@ def main():
     if world == 1:
         emit(extras)
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as e:                               # e.g. a peer that left through the deadline above
+            print(f"[bench] process-group shutdown: {type(e).__name__}: {e}"[:300], file=sys.stderr, flush=True)
 
 
 if __name__ == "__main__":
