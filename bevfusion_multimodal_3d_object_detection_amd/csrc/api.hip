@@ -10,5 +10,5 @@ void bevf_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int bevf_version(void) { return 210; }  // 0.2.1: round 2 -- decode / conv descriptors grew; Winograd forward + weight gradient, fused stem + pool entries
+extern "C" int bevf_version(void) { return 220; }  // 0.2.2: round 2 -- decode / conv descriptors grew; Winograd forward + weight gradient, fused stem + pool, fused PointNet front entries
 extern "C" const char* bevf_last_error(void) { return g_err; }
