@@ -127,35 +127,47 @@ __global__ __launch_bounds__(256, 2) void pointnet_front(FrontArgs a) {
     BEVF_LOAD_GROUP(wb, 24)
     BEVF_MFMA_GROUP_L2(wa, 2)
     __builtin_amdgcn_sched_barrier(0);
-    // layer-3 fragments are [mb][kb][j]: group (mp, kb) = 4 of row block 2*mp (q = 0..3) then 4 of row block 2*mp+1, 16 apart
-#define BEVF_LOAD_GROUP_L3(W, MP, KB)                                                                    \
-    _Pragma("unroll") for (int q = 0; q < 8; ++q) W[q] = frag_load(r3, ulane, (unsigned)((((2 * (MP) + (q >> 2)) * 4 + (KB)) * 4 + (q & 3)) * 1024)); \
+    // Layer 3 walks 16 STEPS per pair of row blocks (step s: input block s / 4, j = s % 4; two fragments, 8 MFMAs on two
+    // independent accumulators) behind a RING of 8 fragment pairs: the pair of step s+7 is requested before the MFMAs of step s
+    // are issued.  Stores share `vmcnt` with the loads on gfx950, so a wait for fragments requested AFTER a row block's stores
+    // also waits for their write acknowledgements: with the ring that first happens 7 steps (56 MFMAs) after the stores, not
+    // one group (32) as with two alternating register sets -- same 64 registers.
+    f32x4 ring[8][2];
+#define BEVF_LOAD_STEP(SLOT, MP, S)                                                                            \
+    ring[SLOT][0] = frag_load(r3, ulane, (unsigned)(((2 * (MP)) * 16 + (S)) * 1024));                         \
+    ring[SLOT][1] = frag_load(r3, ulane, (unsigned)(((2 * (MP) + 1) * 16 + (S)) * 1024));                     \
     __builtin_amdgcn_sched_barrier(0);
-    BEVF_LOAD_GROUP_L3(wa, 0, 0)
+    BEVF_LOAD_STEP(0, 0, 0)                                // wa's registers are free from here on
+    BEVF_LOAD_STEP(1, 0, 1)
+    BEVF_LOAD_STEP(2, 0, 2)
+    BEVF_LOAD_STEP(3, 0, 3)
     BEVF_MFMA_GROUP_L2(wb, 3)
     __builtin_amdgcn_sched_barrier(0);
+    BEVF_LOAD_STEP(4, 0, 4)
+    BEVF_LOAD_STEP(5, 0, 5)
+    BEVF_LOAD_STEP(6, 0, 6)
 
     float* yp = a.y + (size_t)m * C3 + 4 * h;
-#define BEVF_MFMA_GROUP_L3(W, KB)                                                                          \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                          \
-      _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                      \
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(W[j][r], h2[KB][4 * j + r], acc0, 0, 0, 0);            \
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(W[4 + j][r], h2[KB][4 * j + r], acc1, 0, 0, 0);        \
-      }                                                                                                    \
+#define BEVF_MFMA_STEP(S)                                                                                      \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                            \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[(S) & 7][0][r], h2[(S) >> 2][4 * ((S) & 3) + r], acc0, 0, 0, 0); \
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[(S) & 7][1][r], h2[(S) >> 2][4 * ((S) & 3) + r], acc1, 0, 0, 0); \
+    }                                                                                                          \
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
     for (int mp = 0; mp < 4; ++mp) {
       f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       f32x16 acc1 = acc0;
-      BEVF_LOAD_GROUP_L3(wb, mp, 1)
-      BEVF_MFMA_GROUP_L3(wa, 0)
-      BEVF_LOAD_GROUP_L3(wa, mp, 2)
-      BEVF_MFMA_GROUP_L3(wb, 1)
-      BEVF_LOAD_GROUP_L3(wb, mp, 3)
-      BEVF_MFMA_GROUP_L3(wa, 2)
-      const int mpn = mp < 3 ? mp + 1 : 3;               // the last round re-reads its own first group (in bounds, unused)
-      BEVF_LOAD_GROUP_L3(wa, mpn, 0)
-      BEVF_MFMA_GROUP_L3(wb, 3)
+      const int mpn = mp < 3 ? mp + 1 : 3;               // the last round re-reads its own first steps (in bounds, unused)
+#pragma unroll
+      for (int st = 0; st < 16; ++st) {
+        if (st < 9) {
+          BEVF_LOAD_STEP((st + 7) & 7, mp, st + 7)
+        } else {
+          BEVF_LOAD_STEP((st + 7) & 7, mpn, st - 9)
+        }
+        BEVF_MFMA_STEP(st)
+      }
       if (ok) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -172,10 +184,10 @@ __global__ __launch_bounds__(256, 2) void pointnet_front(FrontArgs a) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+#undef BEVF_LOAD_STEP
+#undef BEVF_MFMA_STEP
 #undef BEVF_MFMA_GROUP_L2
-#undef BEVF_MFMA_GROUP_L3
 #undef BEVF_LOAD_GROUP
-#undef BEVF_LOAD_GROUP_L3
   }
 }
 
