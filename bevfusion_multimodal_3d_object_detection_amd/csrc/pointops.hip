@@ -103,8 +103,11 @@ __global__ __launch_bounds__(256) void radar_mlp_max(const RadarArgs a) {
   }
 }
 
-// ---- dense layer, small batch: one wave per output row, weights streamed once -----------------
-template <int NB, typename TW, typename TY>      // x is always fp32 (a small B x K matrix); weights / outputs fp32 or bf16
+// ---- dense layer, small batch: a wave owns R consecutive output rows at a time, weights streamed once -----------------
+// The loads of the R rows are issued together (R x 16 B per lane in flight: one row at a time left the wave waiting out a full
+// HBM round trip per 2 KB of weights); every row keeps its own accumulators, lane partition, FMA order and shuffle tree, so the
+// values do not depend on R.
+template <int NB, int R, typename TW, typename TY>      // x is always fp32 (a small B x K matrix); weights / outputs fp32 or bf16
 __global__ __launch_bounds__(256) void linear_gemv(const float* __restrict__ x, const TW* __restrict__ w,
                                                     const float* __restrict__ bias, TY* __restrict__ y, int K,
                                                     int O, int relu, int perm_inner, int perm_outer) {
@@ -112,33 +115,51 @@ __global__ __launch_bounds__(256) void linear_gemv(const float* __restrict__ x, 
   const int lane = threadIdx.x & 63;
   const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
   const int kv = K / V;
-  for (int o = wave_global; o < O; o += nwaves) {
-    const TW* wr = w + (size_t)o * K;
-    float acc[NB];
+  for (int o0 = wave_global * R; o0 < O; o0 += nwaves * R) {
+    float acc[R][NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) acc[b] = 0.f;
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) acc[r][b] = 0.f;
     for (int i = lane; i < kv; i += 64) {
-      float wv[V];
-      load16(wr + i * V, wv);
+      float wv[R][V];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int o = o0 + r < O ? o0 + r : O - 1;                  // past the end: re-read the last row, never stored
+        load16(w + (size_t)o * K + i * V, wv[r]);
+      }
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         const float* xb = x + (size_t)b * K + i * V;
+        float xv[V];
 #pragma unroll
-        for (int j = 0; j < V; ++j) acc[b] = fmaf(wv[j], xb[j], acc[b]);
+        for (int j = 0; j < V; ++j) xv[j] = xb[j];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int j = 0; j < V; ++j) acc[r][b] = fmaf(wv[r][j], xv[j], acc[r][b]);
       }
     }
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-#pragma unroll
-      for (int s = 32; s >= 1; s >>= 1) acc[b] += __shfl_xor(acc[b], s);
-    }
-    if (lane == 0) {
-      const int oo = perm_inner > 0 ? (o % perm_inner) * perm_outer + o / perm_inner : o;
-      const float bv = bias ? bias[o] : 0.f;
+    for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
-        const float v = acc[b] + bv;
-        y[(size_t)b * O + oo] = (TY)((relu && !(v > 0.f)) ? 0.f : v);
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) acc[r][b] += __shfl_xor(acc[r][b], s);
+      }
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int o = o0 + r;
+        if (o < O) {
+          const int oo = perm_inner > 0 ? (o % perm_inner) * perm_outer + o / perm_inner : o;
+          const float bv = bias ? bias[o] : 0.f;
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            const float v = acc[r][b] + bv;
+            y[(size_t)b * O + oo] = (TY)((relu && !(v > 0.f)) ? 0.f : v);
+          }
+        }
       }
     }
   }
@@ -221,26 +242,33 @@ static int linear_entry(const float* x, const void* w, const float* bias, void* 
   BEVF_REQUIRE(bevf_aligned16(x) && bevf_aligned16(w), "linear: x/w unaligned");
   BEVF_REQUIRE(perm_inner <= 0 || (long long)perm_inner * perm_outer == O, "linear: perm_inner*perm_outer != O");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const unsigned grid = (unsigned)((O + 3) / 4 > 4096 ? 4096 : (O + 3) / 4);
+  // R rows in flight per wave (4 at NB = 8, else 8) when that still leaves every CU several workgroups; small layers keep one
+  // row per wave (more waves, shorter chains).  One step per wave where that fits: workgroups are handed out as others
+  // finish, which balances better than a fixed stride over a ragged number of steps.
+  const bool wide = O >= 16384;
+  auto grid_for = [&](int R) { const int g = (O + 4 * R - 1) / (4 * R); return dim3((unsigned)(g > 16384 ? 16384 : g)); };
+#define BEVF_GEMV(NBv, Rv) \
+  hipLaunchKernelGGL((linear_gemv<NBv, Rv, TW, TY>), grid_for(Rv), dim3(256), 0, st, xb, wt, bias, yb, K, O, relu, perm_inner, perm_outer)
   const TW* wt = static_cast<const TW*>(w);
   for (int b0 = 0; b0 < B;) {
     const int rem = B - b0;
     const float* xb = x + (size_t)b0 * K;
     TY* yb = static_cast<TY*>(y) + (size_t)b0 * O;
     if (rem >= 8) {
-      hipLaunchKernelGGL((linear_gemv<8, TW, TY>), dim3(grid), dim3(256), 0, st, xb, wt, bias, yb, K, O, relu, perm_inner, perm_outer);
+      if (wide) BEVF_GEMV(8, 4); else BEVF_GEMV(8, 1);
       b0 += 8;
     } else if (rem >= 4) {
-      hipLaunchKernelGGL((linear_gemv<4, TW, TY>), dim3(grid), dim3(256), 0, st, xb, wt, bias, yb, K, O, relu, perm_inner, perm_outer);
+      if (wide) BEVF_GEMV(4, 8); else BEVF_GEMV(4, 1);
       b0 += 4;
     } else if (rem >= 2) {
-      hipLaunchKernelGGL((linear_gemv<2, TW, TY>), dim3(grid), dim3(256), 0, st, xb, wt, bias, yb, K, O, relu, perm_inner, perm_outer);
+      if (wide) BEVF_GEMV(2, 8); else BEVF_GEMV(2, 1);
       b0 += 2;
     } else {
-      hipLaunchKernelGGL((linear_gemv<1, TW, TY>), dim3(grid), dim3(256), 0, st, xb, wt, bias, yb, K, O, relu, perm_inner, perm_outer);
+      if (wide) BEVF_GEMV(1, 8); else BEVF_GEMV(1, 1);
       b0 += 1;
     }
   }
+#undef BEVF_GEMV
   return bevf_check_launch("bevf_linear");
 }
 extern "C" int bevf_linear_f32(const float* x, const float* w, const float* bias, float* y, int B, int K, int O,

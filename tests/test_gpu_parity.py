@@ -164,6 +164,16 @@ def test_linear(gpu, B):
     assert rel_err(y.cpu(), F.relu(x @ w.t() + b)) <= KTOL
     L.linear(x.cuda(), w.cuda(), b.cuda(), y, B, K, O, False, 125, 8)      # permuted store: (B,8,125) -> [B][125][8]
     assert rel_err(y.view(B, 125, 8).permute(0, 2, 1).reshape(B, O).cpu(), x @ w.t() + b) <= KTOL
+    # ragged row counts (from 16384 rows on a wave walks 4 or 8 rows at a time): nothing past the last row, bf16 weights, K = 1024
+    for O2, K2 in ((1003, 512), (5, 1024), (1, 64), (16384 + 3, 128)):       # the last one takes the rows-in-flight variant
+        x2, w2, b2 = synth.normal((B, K2), 64), synth.normal((O2, K2), 65, 0, 0.05), synth.normal((O2,), 66)
+        y2 = torch.full((B * O2 + 16,), -3.0, device=gpu)
+        L.linear(x2.cuda(), w2.cuda(), b2.cuda(), y2, B, K2, O2, False)
+        assert rel_err(y2[:B * O2].view(B, O2).cpu(), x2 @ w2.t() + b2) <= KTOL
+        assert torch.all(y2[B * O2:] == -3.0)
+        wb = w2.cuda().bfloat16()
+        L.linear(x2.cuda(), wb, b2.cuda(), y2, B, K2, O2, False)
+        assert rel_err(y2[:B * O2].view(B, O2).cpu(), x2 @ wb.float().cpu().t() + b2) <= KTOL
 
 
 def test_layout_roundtrip(gpu):

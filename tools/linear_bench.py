@@ -1,0 +1,14 @@
+import sys, torch
+sys.path.insert(0, '/root/repo')
+from bevfusion_multimodal_3d_object_detection_amd import _lib as L
+dev = torch.device('cuda')
+for (B, K, O) in ((8, 512, 80000), (1, 512, 80000), (8, 1024, 512)):
+    x = torch.randn(B, K, device=dev); w = torch.randn(O, K, device=dev) * 0.05; b = torch.randn(O, device=dev); y = torch.empty(B * O, device=dev)
+    for _ in range(3): L.linear(x, w, b, y, B, K, O, False)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): L.linear(x, w, b, y, B, K, O, False)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    print(f"linear B={B} K={K} O={O}: {ms*1e3:7.1f} us  {O*K*4/ms/1e6:7.1f} GB/s")
