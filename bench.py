@@ -331,6 +331,20 @@ def run_leg(config, dtype, mode, batch, steps, warmup, ctx, graph=False, kernel_
     return rec, state
 
 
+def install_exit_guard(seconds: float):
+    """After the headline line has left: end this rank with status 0 once `seconds` have passed, whatever it is doing (a
+    collective of the extra leg that never completes would otherwise end in RCCL's watchdog aborting the rank)."""
+    import threading
+
+    def _deadline():
+        print("[bench extra] deadline reached, leaving with the headline already printed", file=sys.stderr, flush=True)
+        os._exit(0)
+    guard = threading.Timer(seconds, _deadline)
+    guard.daemon = True
+    guard.start()
+    return guard
+
+
 def stub_main(args):
     """BEVF_BENCH_STUB=1: the launcher / rank / barrier / MAX-over-ranks control flow with a CPU stand-in for the step
     (CPU-only rehearsal of `--gpus N`, tests/test_multiproc_gloo.py); prints the same JSON skeleton, no measurements."""
@@ -438,14 +452,7 @@ def main():
         emit([])
         # The headline is out; from here on nothing may change this job's exit status.  A collective of the extra leg that never
         # completes would end in RCCL's watchdog aborting the rank (non-zero exit) after the process-group timeout: leave first.
-        import threading
-
-        def _deadline():
-            print("[bench extra] deadline reached, leaving with the headline already printed", file=sys.stderr, flush=True)
-            os._exit(0)
-        guard = threading.Timer(float(os.environ.get("BEVF_EXTRA_DEADLINE_S", "240")), _deadline)
-        guard.daemon = True
-        guard.start()
+        install_exit_guard(float(os.environ.get("BEVF_EXTRA_DEADLINE_S", "240")))
     extras = []
     for config, dtype, mode, batch, *conv_override in plan:
         if mode == "train":

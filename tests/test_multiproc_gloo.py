@@ -161,3 +161,17 @@ def test_bench_single_rank_and_world_mismatch():
     r, lines = _run_bench(["--gpus", "4", "--steps", "2"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0",
                                                            "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})
     assert r.returncode != 0 and not lines and "--gpus 4" in r.stderr
+
+
+def test_exit_guard_ends_a_stuck_rank_with_status_zero():
+    """bench.py at N > 1: once the headline is printed, a hung extra leg must not change the job's exit status."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; bench.install_exit_guard(0.5); "
+            "time.sleep(60); sys.exit(3)" % root)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=50)
+    assert r.returncode == 0 and time.time() - t0 < 40
+    assert "deadline reached" in r.stderr
