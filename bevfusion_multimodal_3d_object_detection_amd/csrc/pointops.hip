@@ -140,26 +140,34 @@ __global__ __launch_bounds__(256) void linear_gemv(const float* __restrict__ x, 
           for (int j = 0; j < V; ++j) acc[r][b] = fmaf(wv[r][j], xv[j], acc[r][b]);
       }
     }
+    // Per row: the NB accumulators summed over the 64 lanes with the xor-butterfly 32, 16, .., 1 -- TRANSPOSING while more than one
+    // value is left: at mask m a lane keeps the half of its values its bit m selects and adds the partner's copy of that half
+    // (NB - 1 + 6 - log2 NB shuffles a row instead of 6 NB; the same pairs are added at every level, so the same bits).
 #pragma unroll
-    for (int r = 0; r < R; ++r)
+    for (int r = 0; r < R; ++r) {
+      int shift = 6;
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
+      for (int m = 32, cur = NB; m >= 1; m >>= 1) {
+        if (cur > 1) {
+          const bool up = (lane & m) != 0;
 #pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) acc[r][b] += __shfl_xor(acc[r][b], s);
-      }
-    if (lane == 0) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int o = o0 + r;
-        if (o < O) {
-          const int oo = perm_inner > 0 ? (o % perm_inner) * perm_outer + o / perm_inner : o;
-          const float bv = bias ? bias[o] : 0.f;
-#pragma unroll
-          for (int b = 0; b < NB; ++b) {
-            const float v = acc[r][b] + bv;
-            y[(size_t)b * O + oo] = (TY)((relu && !(v > 0.f)) ? 0.f : v);
+          for (int i = 0; i < cur / 2; ++i) {
+            const float send = up ? acc[r][i] : acc[r][i + cur / 2];
+            const float keep = up ? acc[r][i + cur / 2] : acc[r][i];
+            acc[r][i] = keep + __shfl_xor(send, m);
           }
+          cur >>= 1;
+          --shift;
+        } else {
+          acc[r][0] += __shfl_xor(acc[r][0], m);
         }
+      }
+      const int o = o0 + r;
+      if ((lane & ((1 << shift) - 1)) == 0 && o < O) {            // one writer per batch row b
+        const int b = (lane >> shift) & (NB - 1);
+        const int oo = perm_inner > 0 ? (o % perm_inner) * perm_outer + o / perm_inner : o;
+        const float v = acc[r][0] + (bias ? bias[o] : 0.f);
+        y[(size_t)b * O + oo] = (TY)((relu && !(v > 0.f)) ? 0.f : v);
       }
     }
   }
