@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void linear_gemv(const float* __restrict__ x, 
       int shift = 6;
 #pragma unroll
       for (int m = 32, cur = NB; m >= 1; m >>= 1) {
-        if (cur > 1) {
+        if (R > 1 && cur > 1) {                     // one row per wave (small layers: latency-bound) keeps the plain butterfly
           const bool up = (lane & m) != 0;
 #pragma unroll
           for (int i = 0; i < cur / 2; ++i) {
@@ -163,11 +163,28 @@ __global__ __launch_bounds__(256) void linear_gemv(const float* __restrict__ x, 
         }
       }
       const int o = o0 + r;
-      if ((lane & ((1 << shift) - 1)) == 0 && o < O) {            // one writer per batch row b
-        const int b = (lane >> shift) & (NB - 1);
-        const int oo = perm_inner > 0 ? (o % perm_inner) * perm_outer + o / perm_inner : o;
-        const float v = acc[r][0] + (bias ? bias[o] : 0.f);
-        y[(size_t)b * O + oo] = (TY)((relu && !(v > 0.f)) ? 0.f : v);
+      if (R > 1) {
+        if ((lane & ((1 << shift) - 1)) == 0 && o < O) {          // one writer per batch row b
+          const int b = (lane >> shift) & (NB - 1);
+          const int oo = perm_inner > 0 ? (o % perm_inner) * perm_outer + o / perm_inner : o;
+          const float v = acc[r][0] + (bias ? bias[o] : 0.f);
+          y[(size_t)b * O + oo] = (TY)((relu && !(v > 0.f)) ? 0.f : v);
+        }
+      } else {
+#pragma unroll
+        for (int b = 1; b < NB; ++b) {                             // plain butterfly for the remaining accumulators
+#pragma unroll
+          for (int m = 32; m >= 1; m >>= 1) acc[r][b] += __shfl_xor(acc[r][b], m);
+        }
+        if (lane == 0 && o < O) {
+          const int oo = perm_inner > 0 ? (o % perm_inner) * perm_outer + o / perm_inner : o;
+          const float bv = bias ? bias[o] : 0.f;
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            const float v = acc[r][b] + bv;
+            y[(size_t)b * O + oo] = (TY)((relu && !(v > 0.f)) ? 0.f : v);
+          }
+        }
       }
     }
   }
