@@ -50,8 +50,21 @@ CONFIGS = {
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
-PMC_PROFILE_ROUNDS = ("r02", "r01")
+PMC_PROFILE_ROUNDS = ("r03", "r02", "r01")
 DEFAULT_CONV = "wino"
+WINO_EXECUTED = 16.0 / 36.0       # Winograd F(2x2,3x3): 16 multiplies on the matrix pipe per 36 of the direct convolution
+# KernelTimer span -> (kernel the span's launches run on, or None = the implicit-GEMM kernel of the leg's dtype / conv mode;
+#                      share of the span's ALGORITHMIC (direct-convolution) FLOPs the matrix pipe really executes)
+MFMA_SPANS = {
+    "conv_wino_f32": ("wino_f32", WINO_EXECUTED),
+    "conv_dgrad_wino_f32": ("wino_f32", WINO_EXECUTED),          # training: the data gradient runs on the forward kernel
+    "conv_wgrad_wino_f32": ("wino_wgrad_f32", WINO_EXECUTED),
+    "conv_igemm_f32": (None, 1.0),
+    "conv_dgrad_f32": (None, 1.0),
+    "conv_wgrad_f32": ("conv_wgrad_f32", 1.0),
+    "stem_conv7x7_f32": ("stem", 1.0),
+    "pointnet_front_f32": ("pointnet_front", 1.0),
+}
 
 
 def parse_args(argv=None):
@@ -133,20 +146,84 @@ class InputCache:
         self.imgs.clear()
 
 
-def pmc_traffic(config: int, batch: int):
-    """HBM-side bytes per conv launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, see
-    tools/pmc_summary.py); only valid for the configuration the profile was taken on.  bench.py cannot read PMC
-    counters itself (they need rocprofv3 around the process), so the figure is labelled with its source."""
+def pmc_traffic(config: int, dtype: str, mode: str, batch: int, kernel: str):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of THIS leg (FETCH_SIZE x2 + WRITE_SIZE
+    in separate passes, MI355X_MICROARCH.md "HBM"; tools/pmc_summary.py); only valid for the configuration the profile was
+    taken on.  bench.py cannot read PMC counters itself (they need rocprofv3 around the process), so the figure is labelled
+    with its source.  Returns (bytes per launch, source) or None."""
+    tag = f"config{config}" + ("" if dtype == "fp32" else f"_{dtype}") + ("_train" if mode == "train" else "") + f"_b{batch}"
+    want = {"wino_f32": ("wino_f32<",), "wino_wgrad_f32": ("wino_wgrad_f32",), "conv_wgrad_f32": ("conv_wgrad_f32",),
+            "conv_igemm_f32": ("conv_igemm<float", "conv_igemm_hybrid<float"),
+            "conv_igemm_bf16": ("conv_igemm<__bf16", "conv_igemm_hybrid<__bf16", "conv_igemm<__hip_bfloat16",
+                                "conv_igemm_hybrid<__hip_bfloat16", "conv3x3_bf16"),
+            "conv3x3_bf16": ("conv3x3_bf16",),
+            "stem": ("stem_",)}.get(kernel)
+    if not want:
+        return None
     for rnd in PMC_PROFILE_ROUNDS:
-        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_config{config}_b{batch}.json")
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_{tag}.json")
         if os.path.exists(path):
             d = json.load(open(path))
-            conv = [v for k, v in d.items() if k.startswith(("conv_igemm", "wino_f32"))]
-            n = sum(v["launches"] for v in conv)
-            tot = sum(v["launches"] * v["hbm_bytes_per_launch"] for v in conv)
+            hit = [v for k, v in d.items() if k.startswith(want)]
+            n = sum(v["launches"] for v in hit)
             if n:
-                return tot / n, "committed profile: " + os.path.relpath(path, ROOT)
+                return (sum(v["launches"] * v["hbm_bytes_per_launch"] for v in hit) / n,
+                        "committed profile: " + os.path.relpath(path, ROOT))
     return None
+
+
+def mfma_roofline(tot, dtype, conv, mode, timer_steps, timer_elapsed, where):
+    """The leg's `roofline` object from the HIP-event brackets (engine.KernelTimer.totals()).
+
+    frac = EXECUTED matrix-pipe FLOPs / (kernel time x MFMA peak of the kernel's operand type): at most 1 by construction (asserted).
+    The Winograd kernels execute 16/36 of a layer's direct-convolution FLOPs (SURVEY.md 8d tabulates the direct ones); that
+    direct-equivalent rate is reported beside it as `algorithmic_equiv_tflops` and never divided by a peak.  The headline
+    fields describe the DOMINANT kernel alone (most kernel time); `conv_aggregate` covers every convolution launch."""
+    igemm = {"fp32": "conv_igemm_f32", "bf16": "conv_igemm_bf16", "f32x3": "conv_split_f32x3"}[dtype]
+    if dtype == "fp32" and conv == "wino_x3":
+        igemm = "conv_split_f32x3"
+    # f32x3 spends six bf16 MFMA products per algorithmic multiply-add: its ceiling is a sixth of the bf16 peak
+    peaks = {"conv_igemm_f32": PEAK_F32_MFMA_TFLOPS, "conv_igemm_bf16": PEAK_BF16_MFMA_TFLOPS,
+             "conv_split_f32x3": PEAK_BF16_MFMA_TFLOPS / 6.0}
+    per = {}
+    for span, (kernel, share) in MFMA_SPANS.items():
+        t = tot.get(span)
+        if not t or t["ms"] <= 0:
+            continue
+        kernel = kernel or igemm
+        if kernel == "stem":
+            kernel = "stem_pool7x7_bf16mma" if dtype == "bf16" else "stem_conv7x7_f32"
+        d = per.setdefault(kernel, dict(ms=0.0, launches=0, algorithmic=0.0, executed=0.0,
+                                        peak=peaks.get(kernel, PEAK_BF16_MFMA_TFLOPS if kernel.endswith("bf16mma") else PEAK_F32_MFMA_TFLOPS)))
+        d["ms"] += t["ms"]; d["launches"] += t["launches"]; d["algorithmic"] += t["flops"]; d["executed"] += t["flops"] * share
+    convs = {k: v for k, v in per.items() if not k.startswith(("stem", "pointnet_front"))}
+    if not convs:
+        return None
+
+    def rates(v):
+        ex = v["executed"] / (v["ms"] * 1e-3) / 1e12
+        frac = ex / v["peak"]
+        assert 0.0 < frac <= 1.0, f"roofline fraction {frac:.3f} outside (0, 1]: executed-FLOP accounting is wrong"
+        return {"achieved": ex, "peak": v["peak"], "unit": "TFLOP/s", "frac": frac,
+                "algorithmic_equiv_tflops": v["algorithmic"] / (v["ms"] * 1e-3) / 1e12,
+                "launches_per_step": v["launches"] / timer_steps, "avg_launch_ms": v["ms"] / v["launches"],
+                "executed_gflop_per_step": v["executed"] / timer_steps / 1e9,
+                "share_of_step": v["ms"] / (1e3 * timer_elapsed)}
+    dom = max(convs, key=lambda k: convs[k]["ms"])
+    roof = {"kernel": dom, "bound": "mfma"}
+    roof.update(rates(convs[dom]))
+    roof["traffic"], roof["traffic_source"] = None, None
+    roof["measured_over"] = where
+    roof["kernels"] = {k: rates(v) for k, v in per.items() if k != dom}
+    agg_ms = sum(v["ms"] for v in convs.values())
+    agg = {"kernels": sorted(convs), "ms_per_step": agg_ms / timer_steps, "share_of_step": agg_ms / (1e3 * timer_elapsed),
+           "executed_tflops": sum(v["executed"] for v in convs.values()) / (agg_ms * 1e-3) / 1e12,
+           "algorithmic_equiv_tflops": sum(v["algorithmic"] for v in convs.values()) / (agg_ms * 1e-3) / 1e12}
+    if len({v["peak"] for v in convs.values()}) == 1:          # one operand type: the aggregate has a roofline of its own
+        agg["frac"] = agg["executed_tflops"] / convs[dom]["peak"]
+        assert agg["frac"] <= 1.0
+    roof["conv_aggregate"] = agg
+    return roof
 
 
 def host_cores() -> int:
@@ -162,8 +239,19 @@ def host_cores() -> int:
     return n
 
 
-def cpu_baseline(cfg, state_dict, budget_s=12.0):
-    """The oracle (CPU restatement, oracle/ref_model.py) on the host cores, B=1, same synthetic frame."""
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, state_dict, budget_s=8.0):
+    """The oracle (CPU restatement, oracle/ref_model.py) on the host cores, same synthetic frames: B=1 (1 warm-up frame, then
+    up to `budget_s` seconds of frames) and one B=8 batch (SURVEY.md 8d asks for both); `value` is the better of the two."""
     import torch
     from bevfusion_multimodal_3d_object_detection_amd import synth
     from oracle import ref_model
@@ -172,17 +260,27 @@ def cpu_baseline(cfg, state_dict, budget_s=12.0):
     ora = ref_model.make_detector(cfg["modality"], cfg["bev"], cfg["bev"])
     ora.load_state_dict(state_dict)
     ora.eval()
-    imgs, pts, radars = synth.frame_inputs(1, cfg["cams"], cfg["h"], cfg["w"], cfg["points"], 4,
-                                           cfg["radars"], 125, 7, seed=0x5EED + 2000)
+
+    def frames(b):
+        return synth.frame_inputs(b, cfg["cams"], cfg["h"], cfg["w"], cfg["points"], 4, cfg["radars"], 125, 7, seed=0x5EED + 2000)
+    samples = {}
     with torch.no_grad():
+        imgs, pts, radars = frames(1)
         ora(imgs, pts, radars or None)                      # warm-up frame
         n, t0 = 0, time.perf_counter()
         while n < 2 or (time.perf_counter() - t0 < budget_s and n < 8):
             ora(imgs, pts, radars or None)
             n += 1
-        dt = time.perf_counter() - t0
-    return dict(value=n / dt, unit="frames/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{n} frames at B=1 after 1 warm-up, oracle/ref_model.py (PyTorch-CPU fp32), same config")
+        samples["b1"] = {"frames_per_s": n / (time.perf_counter() - t0), "frames": n, "warmup_frames": 1}
+        imgs, pts, radars = frames(8)
+        t0 = time.perf_counter()
+        ora(imgs, pts, radars or None)                      # one batch of 8 (the threads and allocator are warm from B=1)
+        samples["b8"] = {"frames_per_s": 8 / (time.perf_counter() - t0), "frames": 8, "warmup_frames": 0}
+    best = max(samples, key=lambda k: samples[k]["frames_per_s"])
+    return dict(value=samples[best]["frames_per_s"], unit="frames/s", cores=torch.get_num_threads(), kind="port",
+                cpu_model=cpu_model(), samples=samples,
+                sample=f"oracle/ref_model.py (PyTorch-CPU fp32), same config: {samples['b1']['frames']} frames at B=1 after 1 warm-up "
+                       f"frame, then one batch of 8; value = the faster ({best})")
 
 
 def run_leg(config, dtype, mode, batch, steps, warmup, ctx, graph=False, kernel_timer=True, keep_state=False, conv="f32"):
@@ -252,6 +350,7 @@ def run_leg(config, dtype, mode, batch, steps, warmup, ctx, graph=False, kernel_
         replicas.barrier(dist)
         elapsed = time.perf_counter() - t0
         engine.set_timer(None)
+        per_rank_elapsed = replicas.gather_over_ranks(elapsed, dist, dev)
         elapsed = replicas.max_over_ranks(elapsed, dist, dev)
         timer_steps, timer_elapsed = steps, elapsed
         if timer is not None and not timer_in_region:
@@ -274,71 +373,46 @@ def run_leg(config, dtype, mode, batch, steps, warmup, ctx, graph=False, kernel_
            "ms_per_step": 1e3 * elapsed / steps,
            "mode": "inference forward -> 5 head tensors" if mode == "infer"
            else "training step: fwd (train-mode BN) + targets + loss + bwd + grad all-reduce + clip + AdamW"}
+    rec["per_rank_elapsed_s"] = per_rank_elapsed
     if mode == "train" and dist is not None:
         rec["grad_allreduce"] = {"collectives_per_step": reducer.collectives / max(1, warmup + steps + (2 if timer else 0)),
                                  "backend": dist.get_backend(), "ranks": dist.get_world_size()}
     if timer is not None:
         tot = timer.totals()
-        conv = tot.get("conv_igemm_f32")
-        wino = tot.get("conv_wino_f32")
-        executed = conv["flops"] if conv else 0.0                 # FLOPs the matrix pipe really executes
-        wino_flops = wino["flops"] if wino else 0.0
-        if wino:                                                  # Winograd F(2x2,3x3): 16 multiplies per 36 algorithmic ones
-            executed += wino["flops"] * 16.0 / 36.0
-            conv = {k: conv[k] + wino[k] for k in conv} if conv else wino
-        if conv and mode == "train":                          # forward + data-gradient + weight-gradient GEMMs
-            for extra in ("conv_dgrad_f32", "conv_wgrad_f32", "conv_wgrad_wino_f32"):
-                e = tot.get(extra)
-                if e:
-                    conv = {k: conv[k] + e[k] for k in conv}
-                    executed += e["flops"] * (16.0 / 36.0 if extra == "conv_wgrad_wino_f32" else 1.0)
-                    wino_flops += e["flops"] if extra == "conv_wgrad_wino_f32" else 0.0
-        if conv:
-            ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
-            # f32x3 spends six bf16 MFMA products per algorithmic multiply-add: its ceiling is a sixth of the bf16 peak
-            peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "f32x3": PEAK_BF16_MFMA_TFLOPS / 6.0}[dtype]
-            kname = {"fp32": "conv_igemm_f32", "bf16": "conv_igemm_bf16", "f32x3": "conv_split_f32x3"}[dtype]
-            if wino:
-                kname = "conv_wino_f32+conv_igemm_f32"
-            rec["roofline"] = {"kernel": kname if mode == "infer" else "conv fwd + dgrad + wgrad (wino_f32, conv_igemm_f32, "
-                                                                       "wino_wgrad_f32, conv_wgrad_f32)",
-                               "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                               "traffic": None, "traffic_source": None,
-                               "launches_per_step": conv["launches"] / timer_steps,
-                               "avg_launch_ms": conv["ms"] / conv["launches"],
-                               "gflop_per_step": conv["flops"] / timer_steps / 1e9,
-                               "share_of_step": conv["ms"] / (1e3 * timer_elapsed),
-                               "measured_over": "the timed region" if timer_in_region else "2 untimed steps after the timed region"}
-            if wino:
-                # `achieved` counts ALGORITHMIC (direct-convolution) FLOPs, as SURVEY.md 8d tabulates them; the Winograd layers
-                # execute 16/36 of theirs, so the matrix pipe's own utilisation is reported beside it
-                ex = executed / (conv["ms"] * 1e-3) / 1e12
-                rec["roofline"]["executed"] = {"tflops": ex, "frac": ex / peak, "wino_share_of_flops": wino_flops / conv["flops"]}
-            tr = pmc_traffic(config, batch) if dtype == "fp32" and mode == "infer" else None
+        roof = mfma_roofline(tot, dtype, conv, mode, timer_steps, timer_elapsed,
+                             "the timed region" if timer_in_region else "2 untimed steps after the timed region")
+        if roof is not None:
+            tr = pmc_traffic(config, dtype, mode, batch, roof["kernel"])
             if tr is not None:
-                rec["roofline"]["traffic"], rec["roofline"]["traffic_source"] = tr
+                roof["traffic"], roof["traffic_source"] = tr
+            rec["roofline"] = roof
         pool = tot.get("bev_pool")
         if pool:
             gbs = pool["bytes"] / (pool["ms"] * 1e-3) / 1e9
             rec["roofline_bev_pool"] = {"kernel": "cam_mean+bilinear_nhwc", "bound": "hbm", "achieved": gbs,
                                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                                         "traffic": None, "mb_per_step": pool["bytes"] / timer_steps / 1e6}
-        stem = tot.get("stem_conv7x7_f32")
-        if stem:
-            rec["stem_tflops"] = stem["flops"] / (stem["ms"] * 1e-3) / 1e12
     del model, inputs, out
     torch.cuda.empty_cache()
     return rec, state
 
 
+EXTRA_DEADLINE_STATUS = 3
+
+
 def install_exit_guard(seconds: float):
-    """After the headline line has left: end this rank with status 0 once `seconds` have passed, whatever it is doing (a
-    collective of the extra leg that never completes would otherwise end in RCCL's watchdog aborting the rank)."""
+    """N > 1, after the headline line has left: if the extra (data-parallel training) leg is still running after `seconds`
+    -- i.e. a gradient all-reduce never completed -- report it as an error record on stderr and END THE RANK WITH A NON-ZERO
+    STATUS: a hung collective must reach the launcher as a failure, never as success.  The deadline sits
+    below the process-group timeout (BEVF_DIST_TIMEOUT_S) so this message, not RCCL's watchdog abort, is what the log shows.
+    Returns the timer; cancel() it once the leg has completed."""
     import threading
 
     def _deadline():
-        print("[bench extra] deadline reached, leaving with the headline already printed", file=sys.stderr, flush=True)
-        os._exit(0)
+        print("[bench extra] " + json.dumps({"error": f"deadline: the extra leg did not complete within {seconds:.0f} s "
+                                                      "(hung collective?); headline already printed, exiting non-zero"}),
+              file=sys.stderr, flush=True)
+        os._exit(EXTRA_DEADLINE_STATUS)
     guard = threading.Timer(seconds, _deadline)
     guard.daemon = True
     guard.start()
@@ -425,19 +499,26 @@ def main():
         }
         if args.mode == "train":
             line["metric"] = "training frames/sec (camera+LiDAR, per-GPU batch 8)"
-        for k in ("roofline", "roofline_bev_pool", "stem_tflops", "grad_allreduce"):
+        for k in ("roofline", "roofline_bev_pool", "grad_allreduce"):
             if k in head:
                 line[k] = head[k]
         if world == 1 and not args.no_cpu_baseline and args.mode == "infer":
             line["cpu_baseline"] = cpu_baseline(cfg, state)
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+        if world > 1:                                        # a straggler must be visible in the line itself
+            line["per_rank"] = {"ms_per_step": [1e3 * t / args.steps for t in head["per_rank_elapsed_s"]],
+                                "frames_per_s": [args.batch * args.steps / t for t in head["per_rank_elapsed_s"]],
+                                "ms_per_step_min": 1e3 * min(head["per_rank_elapsed_s"]) / args.steps,
+                                "ms_per_step_max": 1e3 * max(head["per_rank_elapsed_s"]) / args.steps}
         if extras:
             line["extra"] = {"configs": extras}
         print(json.dumps(line), flush=True)
 
     plan = []
     if args.extras != "none" and not args.graph:
-        plan = [(3, "bf16", "infer", 8), (5, "bf16", "infer", 2), (4, "fp32", "train", 8)]
+        # config 1 = the shape the reference itself runs (ref src/fusion.py:1228-1330: camera_only, B=1, 6x448x800), then B=8
+        plan = [(3, "bf16", "infer", 8), (5, "bf16", "infer", 2), (1, "fp32", "infer", 1), (1, "fp32", "infer", 8),
+                (4, "fp32", "train", 8)]
         if args.conv == "wino" and args.dtype == "fp32" and args.mode == "infer" and args.config == 2 and world == 1:
             # the headline's workload once more with the opt-in mixed convolution mode (NOT the headline: its non-Winograd layers
             # multiply through three bf16 planes instead of fp32 FMAs; fp32-level error)
@@ -448,12 +529,15 @@ def main():
     # N > 1: the ONE JSON line (the replica headline the scaling curve is computed from) leaves BEFORE the extra leg, whose
     # gradient all-reduce is the only collective of this program: if RCCL misbehaves there, the headline is already out.  The
     # leg's record then goes to stderr (`[bench extra] {...}`).  N = 1: no collective anywhere, one line at the end with everything.
+    guard = None
     if world > 1:
         emit([])
-        # The headline is out; from here on nothing may change this job's exit status.  A collective of the extra leg that never
-        # completes would end in RCCL's watchdog aborting the rank (non-zero exit) after the process-group timeout: leave first.
-        install_exit_guard(float(os.environ.get("BEVF_EXTRA_DEADLINE_S", "240")))
+        # The headline is out.  The extra leg's gradient all-reduce is this program's only data-path collective; if it never
+        # completes the rank reports that and exits NON-ZERO (install_exit_guard) -- a hang is a failure, not a success.
+        if plan:
+            guard = install_exit_guard(float(os.environ.get("BEVF_EXTRA_DEADLINE_S", "240")))
     extras = []
+    failed = False
     for config, dtype, mode, batch, *conv_override in plan:
         if mode == "train":
             ctx["inputs"].drop()
@@ -461,11 +545,16 @@ def main():
             rec, _ = run_leg(config, dtype, mode, batch, args.extra_steps, 2, ctx, conv=conv_override[0] if conv_override else args.conv)
             if conv_override:
                 rec["conv_kernels"] = conv_override[0]
-        except Exception as e:                               # a failed extra never takes the headline with it
+        except Exception as e:                               # the headline stays; the failure is recorded AND reflected in the status at N > 1
             rec = {"workload": CONFIGS[config]["name"], "dtype": dtype, "error": f"{type(e).__name__}: {e}"[:300]}
+            failed = True
+        if world == 1:
+            rec.pop("per_rank_elapsed_s", None)
         extras.append(rec)
         if world > 1 and rank == 0:
             print("[bench extra] " + json.dumps(rec), file=sys.stderr, flush=True)
+    if guard is not None:
+        guard.cancel()
     if world == 1:
         emit(extras)
     if dist is not None:
@@ -474,6 +563,9 @@ def main():
             dist.destroy_process_group()
         except Exception as e:                               # e.g. a peer that left through the deadline above
             print(f"[bench] process-group shutdown: {type(e).__name__}: {e}"[:300], file=sys.stderr, flush=True)
+            failed = True
+    if world > 1 and failed:
+        sys.exit(EXTRA_DEADLINE_STATUS)
 
 
 if __name__ == "__main__":

@@ -355,7 +355,7 @@ class PointNetEngine(_Engine):
         if self.front is not None:
             l2, l3 = self.layers[0], self.layers[1]
             a = self.buf("l2", M * l3.cout)
-            with _span("conv_igemm_f32", flops=2.0 * M * (l2.cin * l2.cout + l3.cin * l3.cout)):     # the two MFMA layers
+            with _span("pointnet_front_f32", flops=2.0 * M * (l2.cin * l2.cout + l3.cin * l3.cout)):     # the two MFMA layers
                 L.pointnet_front(pts.float(), self.w0, self.s0, self.b0, self.front[0], l2.scale, l2.shift, self.front[1],
                                  l3.scale, l3.shift, a, M, Cc)
             rest = list(enumerate(self.layers[:-1]))[2:]

@@ -55,6 +55,18 @@ def max_over_ranks(value: float, dist, device: torch.device) -> float:
     return float(t.item())
 
 
+def gather_over_ranks(value: float, dist, device: torch.device) -> List[float]:
+    """Every rank's value, in rank order, on every rank (bench.py: per-rank step times, so a straggler shows)."""
+    if dist is None:
+        return [value]
+    if dist.get_backend() == "gloo":
+        device = torch.device("cpu")
+    mine = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]
+
+
 def aggregate_fps(frames_per_rank: int, world: int, elapsed_max_s: float) -> float:
     """Whole-job throughput: all ranks' frames over the slowest rank's time."""
     return world * frames_per_rank / elapsed_max_s

@@ -166,7 +166,8 @@ def conv_wgrad(x, dy, N, H, W, cin, cout, k, stride, pad, dw=None) -> torch.Tens
             conv_wgrad(x[i0 * H * W * cin:], dy[i0 * Ho * Wo * cout:], n, H, W, cin, cout, k, stride, pad, dw=dw)
         return dw[:cout * k * k * cin].view(cout, k, k, cin)
     flops = 2.0 * N * Ho * Wo * cout * k * k * cin
-    ws = _lib().bevf_wino_wgrad_workspace_floats(N, H, W, cin, cout) if WINO_WGRAD and (k, stride, pad) == (3, 1, 1) else 0
+    ws = (_lib().bevf_wino_wgrad_workspace_floats(N, H, W, cin, cout)
+          if WINO_WGRAD and E.conv_mode() in ("wino", "wino_x3") and (k, stride, pad) == (3, 1, 1) else 0)
     if ws:
         if fresh:
             dw = _new(cout * 9 * cin, x.device)
@@ -254,8 +255,9 @@ def conv_dgrad(dy, weight_oihw, N, H, W, cin, cout, k, stride, pad, add=None, bn
     else:
         assert (Ho, Wo) == (H, W), "stride-1 convs on this path keep the spatial size"
     dx = _new(N * H * W * cin, dy.device)
-    with E._span("conv_dgrad_f32", flops=flops):
-        if stride == 1 and _wino_ok(cout, k, 1, k - 1 - pad):
+    wino = stride == 1 and _wino_ok(cout, k, 1, k - 1 - pad)
+    with E._span("conv_dgrad_wino_f32" if wino else "conv_dgrad_f32", flops=flops):     # (own span name: bench.py prices the 16/36)
+        if wino:
             part = None
             if bnb is not None:
                 G = _lib().bevf_wino_stat_rows(N, sh, sw)

@@ -1,4 +1,5 @@
 """world_size-2 gloo test of the N>1 path bench.py uses (frame sharding + barrier + MAX over ranks). CPU only."""
+import json
 import os
 import socket
 
@@ -163,15 +164,21 @@ def test_bench_single_rank_and_world_mismatch():
     assert r.returncode != 0 and not lines and "--gpus 4" in r.stderr
 
 
-def test_exit_guard_ends_a_stuck_rank_with_status_zero():
-    """bench.py at N > 1: once the headline is printed, a hung extra leg must not change the job's exit status."""
+def test_exit_guard_ends_a_stuck_rank_with_a_failure_status():
+    """bench.py at N > 1: a hung extra leg (a collective that never completes) ends the rank with a NON-ZERO status and an error
+    record on stderr -- a hang must reach the launcher as a failure; a leg that completes cancels the guard."""
     import subprocess
     import sys
     import time
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import sys, time; sys.path.insert(0, %r); import bench; bench.install_exit_guard(0.5); "
-            "time.sleep(60); sys.exit(3)" % root)
+            "time.sleep(60); sys.exit(0)" % root)
     t0 = time.time()
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=50)
-    assert r.returncode == 0 and time.time() - t0 < 40
-    assert "deadline reached" in r.stderr
+    assert r.returncode != 0 and r.returncode == 3 and time.time() - t0 < 40
+    rec = [l for l in r.stderr.splitlines() if l.startswith("[bench extra] ")]
+    assert rec and "deadline" in json.loads(rec[0][len("[bench extra] "):])["error"]
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; g = bench.install_exit_guard(0.5); g.cancel(); "
+            "time.sleep(1.5); sys.exit(0)" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=50)
+    assert r.returncode == 0 and "deadline" not in r.stderr
