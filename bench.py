@@ -60,6 +60,7 @@ MFMA_SPANS = {
     "conv_dgrad_wino_f32": ("wino_f32", WINO_EXECUTED),          # training: the data gradient runs on the forward kernel
     "conv_wgrad_wino_f32": ("wino_wgrad_f32", WINO_EXECUTED),
     "conv_igemm_f32": (None, 1.0),
+    "conv3x3_bf16": ("conv3x3_bf16", 1.0),                       # bf16 models: the 3x3 / stride 1 layers (csrc/conv3x3_bf16.hip)
     "conv_dgrad_f32": (None, 1.0),
     "conv_wgrad_f32": ("conv_wgrad_f32", 1.0),
     "stem_conv7x7_f32": ("stem", 1.0),
@@ -183,7 +184,7 @@ def mfma_roofline(tot, dtype, conv, mode, timer_steps, timer_elapsed, where):
     if dtype == "fp32" and conv == "wino_x3":
         igemm = "conv_split_f32x3"
     # f32x3 spends six bf16 MFMA products per algorithmic multiply-add: its ceiling is a sixth of the bf16 peak
-    peaks = {"conv_igemm_f32": PEAK_F32_MFMA_TFLOPS, "conv_igemm_bf16": PEAK_BF16_MFMA_TFLOPS,
+    peaks = {"conv_igemm_f32": PEAK_F32_MFMA_TFLOPS, "conv_igemm_bf16": PEAK_BF16_MFMA_TFLOPS, "conv3x3_bf16": PEAK_BF16_MFMA_TFLOPS,
              "conv_split_f32x3": PEAK_BF16_MFMA_TFLOPS / 6.0}
     per = {}
     for span, (kernel, share) in MFMA_SPANS.items():

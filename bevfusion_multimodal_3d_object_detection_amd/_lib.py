@@ -128,6 +128,10 @@ SIGNATURES = {
     "bevf_split_weights_f32x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "bevf_conv2d_nhwc_f32x3": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "bevf_conv2d_nhwc_bf16": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "bevf_conv3x3_pack_elems": (C.c_size_t, [C.c_int] * 2),
+    "bevf_conv3x3_bf16_ct": (C.c_int, [C.c_int]),
+    "bevf_conv3x3_pack_bf16": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 2 + [C.c_void_p]),
+    "bevf_conv3x3_bf16": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "bevf_stem_pack_bf16": (C.c_int, [C.c_void_p] * 3),
     "bevf_stem_conv7x7_bf16mma": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_stem_pool_bf16mma": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p]),
@@ -307,6 +311,39 @@ def conv3x3_wino(x: torch.Tensor, u: torch.Tensor, scale, shift, y: torch.Tensor
         d.bnb_mean, d.bnb_invstd = _p(bnb["mean"]), _p(bnb["invstd"])
         d.bnb_gamma, d.bnb_beta = _p(bnb.get("gamma")), _p(bnb.get("beta"))
     _check(lib().bevf_conv3x3_wino_f32(C.byref(d), _stream()), "bevf_conv3x3_wino_f32")
+
+
+def conv3x3_pack_bf16(w_ohwi: torch.Tensor, Cout: int, Cin: int) -> torch.Tensor:
+    """bf16 OHWI 3x3 filter -> the MFMA-fragment-ordered filter image of bevf_conv3x3_bf16."""
+    w_ohwi = w_ohwi.contiguous()
+    if w_ohwi.dtype != torch.bfloat16 or w_ohwi.numel() != Cout * 9 * Cin:
+        raise BevfError(f"conv3x3_pack: need a bf16 filter of {Cout * 9 * Cin} elements, got {w_ohwi.dtype} x {w_ohwi.numel()}")
+    out = torch.empty(lib().bevf_conv3x3_pack_elems(Cout, Cin), dtype=torch.bfloat16, device=w_ohwi.device)
+    _check(lib().bevf_conv3x3_pack_bf16(_pc(w_ohwi, torch.bfloat16), _p(out, torch.bfloat16), Cout, Cin, _stream()),
+           "bevf_conv3x3_pack_bf16")
+    return out
+
+
+def conv3x3_bf16(x: torch.Tensor, wp: torch.Tensor, scale, shift, y: torch.Tensor, *, N: int, H: int, W: int, Cin: int,
+                 x_cs: int, Cout: int, y_cs: int, relu: bool, res: Optional[torch.Tensor] = None, res_cs: int = 0) -> None:
+    """3x3 / stride 1 / pad 1 convolution of bf16 activations (fp32 accumulate, folded BN, residual, ReLU); `wp` from
+    conv3x3_pack_bf16."""
+    M = N * H * W
+    dt = torch.bfloat16
+    if x.numel() < (M - 1) * x_cs + Cin:
+        raise BevfError("conv3x3_bf16: input buffer smaller than N*H*W*x_cs")
+    if wp.dtype != dt or wp.numel() != lib().bevf_conv3x3_pack_elems(Cout, Cin):
+        raise BevfError("conv3x3_bf16: packed filter has the wrong size / dtype")
+    if y.numel() < (M - 1) * y_cs + Cout:
+        raise BevfError("conv3x3_bf16: output buffer too small")
+    if res is not None and res.numel() < (M - 1) * res_cs + Cout:
+        raise BevfError("conv3x3_bf16: residual buffer too small")
+    for v in (scale, shift):
+        if v is not None and v.numel() != Cout:
+            raise BevfError("conv3x3_bf16: scale/shift length != Cout")
+    d = ConvDesc(_p(x, dt), _pc(wp, dt), _pc(scale), _pc(shift), _p(res, dt), _p(y, dt), None, N, H, W, Cin, x_cs, H, W, Cout,
+                 y_cs, res_cs, 3, 3, 1, 1, int(relu), 0, 0)
+    _check(lib().bevf_conv3x3_bf16(C.byref(d), _stream()), "bevf_conv3x3_bf16")
 
 
 def split_weights_f32x3(w: torch.Tensor) -> torch.Tensor:

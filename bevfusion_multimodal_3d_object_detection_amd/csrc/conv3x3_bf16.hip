@@ -1,0 +1,312 @@
+// bf16 direct convolution for the 3x3 / stride 1 / pad 1 layers on v_mfma_f32_16x16x32_bf16 (fp32 accumulate), gfx950.
+//
+// Why its own kernel (round 3): the implicit-GEMM template (conv_igemm.hip) was designed for the fp32 MFMA and is
+// LDS-port-bound at the bf16 MFMA's 16x higher rate -- every K step re-stages a 128-byte A row per output pixel through
+// registers and ds_write, and for a 3x3 layer the same input pixel is staged nine times (once per filter tap).  Here the
+// reuse is explicit:
+//   * a workgroup owns a 16x16 block of output pixels x CT output channels; per 32-channel chunk the 18x18-pixel input
+//     patch is staged ONCE (LDS-DMA, `buffer_load ... lds`, zero fill for padding / image borders by out-of-range
+//     offsets) and all nine taps read their fragments from it at shifted addresses: 7x less global->LDS traffic and no
+//     ds_write at all;
+//   * the filters are packed on the host side of the C-ABI (bevf_conv3x3_pack_bf16) into the exact MFMA fragment order,
+//     one CT x 32 slice per (chunk, tap) step, so staging them is a straight LDS-DMA copy into a small ring and the
+//     fragment reads are lane-linear (bank-conflict-free);
+//   * the patch image is [pixel][4 x 16 B] with the 16-byte piece index XOR-swizzled by ((pixel >> 2) & 1) << 1: the
+//     ds_read_b128 of a 16-pixel row segment (lane = pixel, lane>>4 = k group) then touches every bank exactly once in
+//     each of the instruction's four lane groups, for every tap shift (MI355X_MICROARCH.md "LDS");
+//   * C^T orientation: the MFMA's A operand is the filter fragment, B the pixels, so a lane ends up with 4 consecutive
+//     output channels of one pixel -> 8-byte bf16x4 stores / residual loads instead of 2-byte ones;
+//   * 64 or 128 accumulator registers per wave and 64-72 KB of LDS: two workgroups per CU, so one workgroup's prologue /
+//     epilogue / barrier waits overlap the other's MFMAs.
+// Every wait is written by hand (`s_waitcnt vmcnt(N)` + `s_barrier` in one asm): through __syncthreads() hipcc drains
+// the LDS-DMA queue (vmcnt(0)) at every barrier.
+#include "conv_common.h"
+
+#include <type_traits>
+
+namespace {
+
+struct C3Args {
+  const void* x;        // bf16 NHWC, channel stride x_cs
+  const void* wp;       // packed filters: [ct][chunk][tap][CT/16][64 lanes][8 bf16]
+  const float* scale;   // [Cout] or null
+  const float* shift;
+  const void* res;      // bf16 NHWC residual or null
+  void* y;              // bf16 NHWC
+  int N, H, W, Cin, x_cs, Cout, y_cs, res_cs, relu;
+  int TBY, TBX, nct;
+  unsigned wbytes;      // size of the packed filter image
+};
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int C3_PW = 18;                                 // patch width / height in pixels
+constexpr int C3_PDMA = 6;                                // LDS-DMA instructions per wave and chunk: 4 x 6 x 64 slots >= 324 x 4
+constexpr int C3_PATCH_BYTES = 4 * C3_PDMA * 64 * 16;     // 24576
+
+// DMA pieces a wave has issued AFTER the filters of step s + 1 by the end of step s (tap t): those filters left first thing in
+// step s + 1 - D; each later step added NBP filter pieces, and each of the D steps one patch piece if its tap is < C3_PDMA
+constexpr int c3_wait_count(int t, int D, int NBP) {
+  int c = (D - 1) * NBP;
+  for (int u = 0; u < D; ++u) c += ((t - u + 9) % 9) < C3_PDMA ? 1 : 0;
+  return c;
+}
+
+template <int CT> struct C3Geo {
+  static constexpr int WN = CT / 64, WM = 4 / WN, MT = 16 / WM, NT = 4;
+  static constexpr int WSTEP = CT * 64;                   // bytes of filters per (chunk, tap) step
+  static constexpr int NBP = CT / 64;                     // filter DMA pieces (1 KiB) per wave and step
+  static constexpr int RB = CT == 64 ? 4 : 3;             // ring slots; a step's filters are requested RB-1 steps ahead
+  static constexpr int LDS_BYTES = 2 * C3_PATCH_BYTES + RB * WSTEP;
+};
+
+template <int CT>
+__global__ __launch_bounds__(256, 2) void conv3x3_bf16(const C3Args p) {
+  using Geo = C3Geo<CT>;
+  constexpr int WN = Geo::WN, MT = Geo::MT, NT = Geo::NT, WSTEP = Geo::WSTEP, NBP = Geo::NBP, RB = Geo::RB, D = RB - 1;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* const patch = lds;                                // [2][C3_PATCH_BYTES]
+  char* const ring = lds + 2 * C3_PATCH_BYTES;            // [RB][WSTEP]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int NCH = p.Cin >> 5, S = 9 * NCH;
+
+  // ---- tile: ct-major numbering, so the workgroups running together share one filter slab in L2; XCD-contiguous ----
+  const int nsp = p.N * p.TBY * p.TBX;
+  const int sid = xcd_remap(blockIdx.x, gridDim.x);
+  const int ct = sid / nsp;
+  int sp = sid - ct * nsp;
+  const int bx = sp % p.TBX;
+  sp /= p.TBX;
+  const int by = sp % p.TBY, n = sp / p.TBY;
+
+  // ---- patch staging: instruction (4 j + wave), j < 6, fills 64 consecutive 16-byte slots; slot i = pixel i >> 2,
+  //      piece (i & 3) ^ swz(pixel): the swizzle sits on the SOURCE address, the LDS image stays lane-linear -----------
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)kOob, 0x00020000);
+  unsigned pv[C3_PDMA];
+  {
+    const int iy0 = 16 * by - 1, ix0 = 16 * bx - 1;
+#pragma unroll
+    for (int j = 0; j < C3_PDMA; ++j) {
+      const int i = (4 * j + wave) * 64 + lane;
+      const int pix = i >> 2, kg = (i & 3) ^ (((pix >> 2) & 1) << 1);
+      const int py = (pix * 3641) >> 16, px = pix - py * C3_PW;            // pix / 18 for pix < 1024
+      const int iy = iy0 + py, ix = ix0 + px;
+      const bool ok = pix < C3_PW * C3_PW && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      pv[j] = ok ? (unsigned)((((n * p.H + iy) * p.W + ix) * p.x_cs + kg * 8) * 2) : kOob;
+    }
+  }
+  auto patch_dma = [&](unsigned voff, unsigned soff, int buf, int j) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+        rsx, (__attribute__((address_space(3))) void*)(patch + buf * C3_PATCH_BYTES + (4 * j + wave) * 1024), 16, voff, soff, 0, 0);
+  };
+
+  // ---- filter ring: the image of step s is WSTEP contiguous bytes at (ct * S + s) * WSTEP; wave w copies pieces w, w+4;
+  //      steps past the end read past num_records and arrive as zeros in a slot nobody reads any more ------------------
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wp), 0, (int)p.wbytes, 0x00020000);
+  const unsigned w_lane = (unsigned)(lane * 16);
+  const unsigned w_tile = (unsigned)(ct * S) * (unsigned)WSTEP;
+  auto ring_dma = [&](int step, int slot) {
+#pragma unroll
+    for (int i = 0; i < NBP; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rsw, (__attribute__((address_space(3))) void*)(ring + slot * WSTEP + (wave + 4 * i) * 1024), 16, w_lane,
+          w_tile + (unsigned)step * (unsigned)WSTEP + (unsigned)((wave + 4 * i) * 1024), 0, 0);
+  };
+
+  // ---- fragment read addresses (bytes).  x: pixel row r of the wave's MT + 2 patch rows, tap column kw ----------------
+  const int col = lane & 15, kgl = lane >> 4;
+  int xa[MT + 2][3];
+#pragma unroll
+  for (int r = 0; r < MT + 2; ++r)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int pix = (wm * MT + r) * C3_PW + kw + col;
+      xa[r][kw] = (pix * 4 + (kgl ^ (((pix >> 2) & 1) << 1))) * 16;
+    }
+  const int wa = 2 * C3_PATCH_BYTES + wn * 4096 + lane * 16;          // + slot * WSTEP + nt * 1024
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: filters of steps 0 .. D-1, patch chunk 0 -----------------------------------------------------------
+#pragma unroll
+  for (int s = 0; s < D; ++s) ring_dma(s, s);
+#pragma unroll
+  for (int j = 0; j < C3_PDMA; ++j) patch_dma(pv[j], 0, 0, j);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+  // One step = one filter tap of one 32-channel chunk: MT x NT MFMAs per wave.  Issue order inside a step: the filter
+  // pieces of step s + D, then (taps 0..5) one sixth of the NEXT chunk's patch; loads retire in order, so the wait at the
+  // step's end -- vmcnt(pieces issued after the filters of step s + 1) -- names exactly those filters and, after tap 8,
+  // the whole next patch chunk; everything younger stays in flight across the barrier.
+  int slot = 0;                                                      // ring slot of the current step
+  auto step = [&](auto tc, const int s, const int pbuf, const unsigned psoff, const bool pnext) {
+    constexpr int t = decltype(tc)::value, kh = t / 3, kw = t % 3;
+    {
+      int ns = slot + D;
+      ns = ns >= RB ? ns - RB : ns;
+      ring_dma(s + D, ns);
+    }
+    if constexpr (t < C3_PDMA) patch_dma(pnext ? pv[t] : kOob, psoff, pbuf ^ 1, t);
+    bf16x8 wf[NT], xf[MT];
+    const char* wb = lds + wa + slot * WSTEP;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wf[nt] = *reinterpret_cast<const bf16x8*>(wb + nt * 1024);
+    const char* pb = patch + pbuf * C3_PATCH_BYTES;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xf[mt] = *reinterpret_cast<const bf16x8*>(pb + xa[mt + kh][kw]);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+    slot = slot + 1 == RB ? 0 : slot + 1;
+    constexpr int cnt = c3_wait_count(t, D, NBP);
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(cnt) : "memory");
+  };
+  using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
+  using T3 = std::integral_constant<int, 3>; using T4 = std::integral_constant<int, 4>; using T5 = std::integral_constant<int, 5>;
+  using T6 = std::integral_constant<int, 6>; using T7 = std::integral_constant<int, 7>; using T8 = std::integral_constant<int, 8>;
+  for (int c = 0; c < NCH; ++c) {
+    const int pbuf = c & 1, s0 = 9 * c;
+    const unsigned psoff = (unsigned)((c + 1) * 64);                 // next chunk: + 32 channels
+    const bool pnext = c + 1 < NCH;
+    step(T0{}, s0 + 0, pbuf, psoff, pnext); step(T1{}, s0 + 1, pbuf, psoff, pnext); step(T2{}, s0 + 2, pbuf, psoff, pnext);
+    step(T3{}, s0 + 3, pbuf, psoff, pnext); step(T4{}, s0 + 4, pbuf, psoff, pnext); step(T5{}, s0 + 5, pbuf, psoff, pnext);
+    step(T6{}, s0 + 6, pbuf, psoff, pnext); step(T7{}, s0 + 7, pbuf, psoff, pnext); step(T8{}, s0 + 8, pbuf, psoff, pnext);
+  }
+
+  // ---- epilogue: acc[nt][mt][j] = channel ct*CT + wn*64 + nt*16 + 4*(lane>>4) + j of pixel (row wm*MT + mt, column lane&15) ----
+  const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)kOob, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, (int)kOob, 0x00020000);
+  const int co0 = ct * CT + wn * 64 + 4 * kgl;
+  const int ox = 16 * bx + col, oy0 = 16 * by + wm * MT;
+  const bool xok = ox < p.W;
+  f32x4 sc[NT], sh[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    sc[nt] = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + co0 + nt * 16) : f32x4{1.f, 1.f, 1.f, 1.f};
+    sh[nt] = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + co0 + nt * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int oy = oy0 + mt;
+    const bool ok = xok && oy < p.H;
+    const unsigned pixel = (unsigned)((n * p.H + oy) * p.W + ox);
+    const unsigned yo = ok ? (pixel * (unsigned)p.y_cs + (unsigned)co0) * 2u : kOob;
+    const unsigned ro = ok ? (pixel * (unsigned)p.res_cs + (unsigned)co0) * 2u : kOob;
+    u32x2 rv[NT];
+    if (p.res) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) rv[nt] = __builtin_amdgcn_raw_buffer_load_b64(rsr, ro, (unsigned)(nt * 32), 0);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = fmaf(acc[nt][mt][j], sc[nt][j], sh[nt][j]);
+      if (p.res) {
+        const bf16x4 r4 = __builtin_bit_cast(bf16x4, rv[nt]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] += (float)r4[j];
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
+      }
+      bf16x4 ob;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ob[j] = (__bf16)o[j];
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), rsy, yo, (unsigned)(nt * 32), 0);
+    }
+  }
+}
+
+// OHWI bf16 filters [Cout][3][3][Cin] -> [ct][chunk][tap][CT/16][lane][8]: element j of lane (m = lane & 15, kg = lane >> 4)
+// of fragment nt is w[ct*CT + nt*16 + m][tap][chunk*32 + kg*8 + j]
+__global__ __launch_bounds__(256) void conv3x3_pack(const unsigned short* __restrict__ w, unsigned short* __restrict__ out, int Cout,
+                                                    int Cin, int CT, long long total) {
+  const long long idx = blockIdx.x * 256ll + threadIdx.x;            // one 16-byte fragment piece each
+  if (idx >= total) return;
+  const int NCH = Cin >> 5, nfr = CT / 16;
+  long long r = idx;
+  const int lane = (int)(r & 63); r >>= 6;
+  const int nt = (int)(r % nfr); r /= nfr;
+  const int tap = (int)(r % 9); r /= 9;
+  const int c = (int)(r % NCH);
+  const int ct = (int)(r / NCH);
+  const int co = ct * CT + nt * 16 + (lane & 15), ci = c * 32 + (lane >> 4) * 8;
+  typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+  u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (co < Cout) v = *reinterpret_cast<const u16x8*>(w + ((size_t)co * 9 + tap) * Cin + ci);
+  *reinterpret_cast<u16x8*>(out + idx * 8) = v;
+}
+
+}  // namespace
+
+// Output-channel tile the kernel will use for a layer (the packed filter image depends on it).
+extern "C" int bevf_conv3x3_bf16_ct(int Cout) { return Cout % 128 == 0 ? 128 : 64; }
+
+extern "C" size_t bevf_conv3x3_pack_elems(int Cout, int Cin) {
+  const int CT = bevf_conv3x3_bf16_ct(Cout);
+  return (size_t)((Cout + CT - 1) / CT) * CT * 9 * (size_t)Cin;
+}
+
+extern "C" int bevf_conv3x3_pack_bf16(const void* w_ohwi, void* packed, int Cout, int Cin, void* stream) {
+  BEVF_REQUIRE(w_ohwi && packed, "conv3x3_pack: null pointer");
+  BEVF_REQUIRE(Cout > 0 && Cin > 0 && Cin % 32 == 0, "conv3x3_pack: Cin=%d must be a positive multiple of 32", Cin);
+  BEVF_REQUIRE(bevf_aligned16(w_ohwi) && bevf_aligned16(packed), "conv3x3_pack: pointers must be 16-byte aligned");
+  const int CT = bevf_conv3x3_bf16_ct(Cout);
+  const long long total = (long long)bevf_conv3x3_pack_elems(Cout, Cin) / 8;
+  hipLaunchKernelGGL(conv3x3_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const unsigned short*>(w_ohwi), static_cast<unsigned short*>(packed), Cout, Cin, CT, total);
+  return bevf_check_launch("bevf_conv3x3_pack_bf16");
+}
+
+extern "C" int bevf_conv3x3_bf16(const bevf_conv_desc* d, void* stream) {
+  BEVF_REQUIRE(d && d->x && d->w && d->y, "conv3x3_bf16: null x / w / y");
+  BEVF_REQUIRE(d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1, "conv3x3_bf16: 3x3, stride 1, pad 1 only (got %dx%d s%d p%d)",
+               d->KH, d->KW, d->stride, d->pad);
+  BEVF_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cout > 0 && d->Ho == d->H && d->Wo == d->W, "conv3x3_bf16: bad shape");
+  BEVF_REQUIRE(d->Cin > 0 && d->Cin % 32 == 0, "conv3x3_bf16: Cin=%d must be a positive multiple of 32", d->Cin);
+  BEVF_REQUIRE(d->Cout % 64 == 0, "conv3x3_bf16: Cout=%d must be a multiple of 64", d->Cout);
+  BEVF_REQUIRE(d->x_cs >= d->Cin && d->x_cs % 8 == 0, "conv3x3_bf16: x_cs=%d must be >= Cin and a multiple of 8", d->x_cs);
+  BEVF_REQUIRE(d->y_cs >= d->Cout && d->y_cs % 4 == 0, "conv3x3_bf16: y_cs=%d must be >= Cout and a multiple of 4", d->y_cs);
+  BEVF_REQUIRE(!d->res || (d->res_cs >= d->Cout && d->res_cs % 4 == 0), "conv3x3_bf16: res_cs must be >= Cout and a multiple of 4");
+  BEVF_REQUIRE(!d->colmax && !d->stats && !d->bnb_x, "conv3x3_bf16: no column max / BatchNorm epilogues (inference kernel)");
+  BEVF_REQUIRE(bevf_aligned16(d->x) && bevf_aligned16(d->w) && (reinterpret_cast<uintptr_t>(d->y) & 7u) == 0 &&
+                   (!d->res || (reinterpret_cast<uintptr_t>(d->res) & 7u) == 0) &&
+                   (!d->scale || bevf_aligned16(d->scale)) && (!d->shift || bevf_aligned16(d->shift)),
+               "conv3x3_bf16: x / w / scale / shift must be 16-byte aligned, y / res 8-byte aligned");
+  BEVF_REQUIRE((long long)d->N * d->H * d->W * d->x_cs * 2 < (1ll << 31) && (long long)d->N * d->H * d->W * d->y_cs * 2 < (1ll << 31) &&
+                   (!d->res || (long long)d->N * d->H * d->W * d->res_cs * 2 < (1ll << 31)),
+               "conv3x3_bf16: activations must stay below 2 GiB (32-bit buffer offsets)");
+  const size_t wbytes = bevf_conv3x3_pack_elems(d->Cout, d->Cin) * 2;
+  BEVF_REQUIRE(wbytes < (1ull << 31), "conv3x3_bf16: packed filters must stay below 2 GiB");
+  C3Args a;
+  a.x = d->x; a.wp = d->w; a.scale = d->scale; a.shift = d->shift; a.res = d->res; a.y = d->y;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.x_cs = d->x_cs; a.Cout = d->Cout; a.y_cs = d->y_cs; a.res_cs = d->res_cs;
+  a.relu = d->relu;
+  a.TBY = (d->H + 15) / 16; a.TBX = (d->W + 15) / 16;
+  a.wbytes = (unsigned)wbytes;
+  const int CT = bevf_conv3x3_bf16_ct(d->Cout);
+  a.nct = d->Cout / CT;
+  const long long ntiles = (long long)d->N * a.TBY * a.TBX * a.nct;
+  BEVF_REQUIRE(ntiles < (1ll << 31), "conv3x3_bf16: too many tiles");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16<64>), hipFuncAttributeMaxDynamicSharedMemorySize, C3Geo<64>::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16<128>), hipFuncAttributeMaxDynamicSharedMemorySize, C3Geo<128>::LDS_BYTES);
+    attr_done = true;
+  }
+  if (CT == 128) hipLaunchKernelGGL((conv3x3_bf16<128>), dim3((unsigned)ntiles), dim3(256), C3Geo<128>::LDS_BYTES, st, a);
+  else hipLaunchKernelGGL((conv3x3_bf16<64>), dim3((unsigned)ntiles), dim3(256), C3Geo<64>::LDS_BYTES, st, a);
+  return bevf_check_launch("bevf_conv3x3_bf16");
+}

@@ -255,6 +255,7 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
     }
 
     asm volatile("s_waitcnt vmcnt(0)");                             // (the last, all-out-of-range patch part: LDS is reused below)
+    if constexpr (STATS || BNB != 0) __syncthreads();              // ... by EVERY wave's zero-writing DMAs before any wave's partial sums land there
     // ---- epilogue: output transform per (tile, channel), scale/shift (+res) (+relu), store ----------------------------
     // acc[f][nb][r]: tile 4 kq + r of this wave = (tile row kq>>1, tile column 4 (kq&1) + r), channel ct*64 + nb*16 + (lane&15)
     {

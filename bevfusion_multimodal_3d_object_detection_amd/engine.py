@@ -47,9 +47,11 @@ class PackedConv:
     pad: int
     relu: bool
     wino: bool = False       # w is the transformed-filter image of the fused Winograd kernel (csrc/conv_wino.hip)
+    c3: bool = False         # w is the fragment-ordered filter image of the bf16 3x3 kernel (csrc/conv3x3_bf16.hip)
 
 
 _CONV_MODE = "wino"
+BF16_CONV3X3 = True          # bf16 models: 3x3 / stride 1 / pad 1 layers on csrc/conv3x3_bf16.hip (False: implicit GEMM everywhere, the round-2 path)
 
 
 def set_conv_mode(mode: str) -> None:
@@ -96,6 +98,9 @@ def _finish_pack(packed, scale, shift, cin, cout, k, stride, pad, relu, split_ok
             return PackedConv(L.wino_filter_transform(packed, cout, cin), scale, shift, cin, cout, k, stride, pad, relu, wino=True)
         if _CONV_MODE in ("f32x3", "wino_x3") and split_ok:
             packed = L.split_weights_f32x3(packed)
+    if (BF16_CONV3X3 and packed.dtype == torch.bfloat16 and (k, stride, pad) == (3, 1, 1) and cin % 32 == 0 and cout % 64 == 0
+            and wino_ok):
+        return PackedConv(L.conv3x3_pack_bf16(packed, cout, cin), scale, shift, cin, cout, k, stride, pad, relu, c3=True)
     return PackedConv(packed, scale, shift, cin, cout, k, stride, pad, relu)
 
 
@@ -119,7 +124,7 @@ class _Engine:
         self._bufs: Dict[str, torch.Tensor] = {}
 
     def _signature(self):
-        return (_CONV_MODE,) + tuple((t.data_ptr(), t._version) for t in self.module.state_dict(keep_vars=True).values())
+        return (_CONV_MODE, BF16_CONV3X3) + tuple((t.data_ptr(), t._version) for t in self.module.state_dict(keep_vars=True).values())
 
     def ensure_packed(self) -> None:
         sig = self._signature()
@@ -209,7 +214,7 @@ def _span(name: str, flops: float = 0.0, nbytes: float = 0.0):
 def _run_conv(pc: PackedConv, x, y, N, H, W, x_cs=None, y_cs=None, res=None, colmax=None, rows_per_group=0, tile=0):
     ho, wo = (H + 2 * pc.pad - pc.k) // pc.stride + 1, (W + 2 * pc.pad - pc.k) // pc.stride + 1
     flops = 2.0 * N * ho * wo * pc.cout * pc.k * pc.k * pc.cin          # algorithmic (direct convolution)
-    with _span("conv_wino_f32" if pc.wino else "conv_igemm_f32", flops=flops):
+    with _span("conv_wino_f32" if pc.wino else ("conv3x3_bf16" if pc.c3 else "conv_igemm_f32"), flops=flops):
         _conv_call(pc, x, y, N, H, W, x_cs, y_cs, res, colmax, rows_per_group, tile)
     return ho, wo
 
@@ -217,6 +222,10 @@ def _run_conv(pc: PackedConv, x, y, N, H, W, x_cs=None, y_cs=None, res=None, col
 def _conv_call(pc: PackedConv, x, y, N, H, W, x_cs=None, y_cs=None, res=None, colmax=None, rows_per_group=0, tile=0):
     if pc.wino:
         L.conv3x3_wino(x, pc.w, pc.scale, pc.shift, y, N=N, H=H, W=W, Cin=pc.cin, x_cs=x_cs or pc.cin, Cout=pc.cout,
+                       y_cs=y_cs or pc.cout, relu=pc.relu, res=res, res_cs=pc.cout if res is not None else 0)
+        return
+    if pc.c3:
+        L.conv3x3_bf16(x, pc.w, pc.scale, pc.shift, y, N=N, H=H, W=W, Cin=pc.cin, x_cs=x_cs or pc.cin, Cout=pc.cout,
                        y_cs=y_cs or pc.cout, relu=pc.relu, res=res, res_cs=pc.cout if res is not None else 0)
         return
     L.conv2d_nhwc(x, pc.w, pc.scale, pc.shift, y, N=N, H=H, W=W, Cin=pc.cin, x_cs=x_cs or pc.cin, Cout=pc.cout,

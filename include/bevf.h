@@ -311,6 +311,17 @@ int bevf_scatter_voxels_f32(const float* features, const int64_t* coords, const 
  * ========================================================================================== */
 int bevf_conv2d_nhwc_bf16(const bevf_conv_desc* d, void* stream);
 
+/* The 3x3 / stride 1 / pad 1 layers of the bf16 path (ResNet blocks ref src/encoders.py:158-160 via torchvision's BasicBlock,
+ * camera_proj / lidar_upsample / bev_fusion ref src/fusion.py:141-207, the CenterNet 3x3 convs ref src/fusion.py:822-854) as a
+ * direct convolution on v_mfma_f32_16x16x32_bf16 that stages each 18x18-pixel input patch ONCE per 32-channel chunk (LDS-DMA)
+ * and reads all nine taps from it; same descriptor as bevf_conv2d_nhwc_bf16 (colmax / stats unsupported, `tile` ignored).
+ * `d->w` = the filter image made by bevf_conv3x3_pack_bf16 from the OHWI bf16 filter (bevf_conv3x3_pack_elems(Cout, Cin)
+ * bf16 elements).  Requires KH = KW = 3, stride 1, pad 1, Cin % 32 == 0, Cout % 64 == 0, x_cs % 8 == 0, y_cs % 4 == 0. */
+size_t bevf_conv3x3_pack_elems(int Cout, int Cin);
+int bevf_conv3x3_bf16_ct(int Cout);   /* output-channel tile (64 | 128) the kernel uses for this layer */
+int bevf_conv3x3_pack_bf16(const void* w_ohwi, void* packed, int Cout, int Cin, void* stream);
+int bevf_conv3x3_bf16(const bevf_conv_desc* d, void* stream);
+
 /* Opt-in "f32x3" convolution: same contract as bevf_conv2d_nhwc_f32 (fp32 activations in and out, no colmax), but
  * the products run on the bf16 MFMA over an exact three-way bf16 split of both operands (six partial products,
  * fp32 accumulate): fp32-level error, not bit-identical to the fp32 FMA chain.  `w` = planes written by
