@@ -325,9 +325,10 @@ def conv3x3_pack_bf16(w_ohwi: torch.Tensor, Cout: int, Cin: int) -> torch.Tensor
 
 
 def conv3x3_bf16(x: torch.Tensor, wp: torch.Tensor, scale, shift, y: torch.Tensor, *, N: int, H: int, W: int, Cin: int,
-                 x_cs: int, Cout: int, y_cs: int, relu: bool, res: Optional[torch.Tensor] = None, res_cs: int = 0) -> None:
+                 x_cs: int, Cout: int, y_cs: int, relu: bool, res: Optional[torch.Tensor] = None, res_cs: int = 0,
+                 tile: int = 0) -> None:
     """3x3 / stride 1 / pad 1 convolution of bf16 activations (fp32 accumulate, folded BN, residual, ReLU); `wp` from
-    conv3x3_pack_bf16."""
+    conv3x3_pack_bf16.  tile (64-channel tiles only): 0 auto, 1 = two patch buffers / two workgroups per CU, 2 = one / four."""
     M = N * H * W
     dt = torch.bfloat16
     if x.numel() < (M - 1) * x_cs + Cin:
@@ -342,7 +343,7 @@ def conv3x3_bf16(x: torch.Tensor, wp: torch.Tensor, scale, shift, y: torch.Tenso
         if v is not None and v.numel() != Cout:
             raise BevfError("conv3x3_bf16: scale/shift length != Cout")
     d = ConvDesc(_p(x, dt), _pc(wp, dt), _pc(scale), _pc(shift), _p(res, dt), _p(y, dt), None, N, H, W, Cin, x_cs, H, W, Cout,
-                 y_cs, res_cs, 3, 3, 1, 1, int(relu), 0, 0)
+                 y_cs, res_cs, 3, 3, 1, 1, int(relu), 0, int(tile))
     _check(lib().bevf_conv3x3_bf16(C.byref(d), _stream()), "bevf_conv3x3_bf16")
 
 

@@ -16,8 +16,8 @@
 //     each of the instruction's four lane groups, for every tap shift (MI355X_MICROARCH.md "LDS");
 //   * C^T orientation: the MFMA's A operand is the filter fragment, B the pixels, so a lane ends up with 4 consecutive
 //     output channels of one pixel -> 8-byte bf16x4 stores / residual loads instead of 2-byte ones;
-//   * 64 or 128 accumulator registers per wave and 64-72 KB of LDS: two workgroups per CU, so one workgroup's prologue /
-//     epilogue / barrier waits overlap the other's MFMAs.
+//   * 64 or 128 accumulator registers per wave and 36-72 KB of LDS: two to four workgroups per CU, so one workgroup's
+//     prologue / epilogue / barrier waits overlap the others' MFMAs.
 // Every wait is written by hand (`s_waitcnt vmcnt(N)` + `s_barrier` in one asm): through __syncthreads() hipcc drains
 // the LDS-DMA queue (vmcnt(0)) at every barrier.
 #include "conv_common.h"
@@ -41,36 +41,38 @@ struct C3Args {
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int C3_PW = 18;                                 // patch width / height in pixels
-constexpr int C3_PDMA = 6;                                // LDS-DMA instructions per wave and chunk: 4 x 6 x 64 slots >= 324 x 4
-constexpr int C3_PATCH_BYTES = 4 * C3_PDMA * 64 * 16;     // 24576
+constexpr int C3_PITCH = 20;                              // patch row pitch in the LDS image, pixels (see the read addresses in the kernel)
+constexpr int C3_PATCH_BYTES = 24 * 1024;                 // 24 LDS-DMA pieces of 64 slots >= 18 x 20 x 4 slots
 
-// DMA pieces a wave has issued AFTER the filters of step s + 1 by the end of step s (tap t): those filters left first thing in
-// step s + 1 - D; each later step added NBP filter pieces, and each of the D steps one patch piece if its tap is < C3_PDMA
-constexpr int c3_wait_count(int t, int D, int NBP) {
-  int c = (D - 1) * NBP;
-  for (int u = 0; u < D; ++u) c += ((t - u + 9) % 9) < C3_PDMA ? 1 : 0;
-  return c;
-}
-
-template <int CT> struct C3Geo {
+// CT = output channels per workgroup (64: waves 4 x 1, 128: waves 2 x 2; a wave always owns 64 channels).
+// PB = patch buffers: 2 = the next 32-channel chunk is prefetched under the current one (two workgroups per CU);
+//      1 = one buffer, 34 KB, FOUR workgroups per CU: occupancy instead of prefetch.
+template <int CT, int PB> struct C3Geo {
   static constexpr int WN = CT / 64, WM = 4 / WN, MT = 16 / WM, NT = 4;
   static constexpr int WSTEP = CT * 64;                   // bytes of filters per (chunk, tap) step
-  static constexpr int NBP = CT / 64;                     // filter DMA pieces (1 KiB) per wave and step
-  static constexpr int RB = CT == 64 ? 4 : 3;             // ring slots; a step's filters are requested RB-1 steps ahead
-  static constexpr int LDS_BYTES = 2 * C3_PATCH_BYTES + RB * WSTEP;
+  static constexpr int RB = (CT == 64 && PB == 2) ? 4 : 3;   // ring slots; a step's filters are requested RB-1 steps ahead
+  static constexpr int LDS_BYTES = PB * C3_PATCH_BYTES + RB * WSTEP;
+  static constexpr int WG_PER_CU = PB == 1 ? 4 : 2;
+  static constexpr bool RES_EARLY = CT == 64 && PB == 2;  // residual requested in the prologue (32 registers; see the kernel)
 };
 
-template <int CT>
-__global__ __launch_bounds__(256, 2) void conv3x3_bf16(const C3Args p) {
-  using Geo = C3Geo<CT>;
-  constexpr int WN = Geo::WN, MT = Geo::MT, NT = Geo::NT, WSTEP = Geo::WSTEP, NBP = Geo::NBP, RB = Geo::RB, D = RB - 1;
+template <int CT, int PB>
+__global__ __launch_bounds__(256, (C3Geo<CT, PB>::WG_PER_CU)) void conv3x3_bf16(const C3Args p) {
+  using Geo = C3Geo<CT, PB>;
+  constexpr int WN = Geo::WN, MT = Geo::MT, NT = Geo::NT, WSTEP = Geo::WSTEP, RB = Geo::RB, D = RB - 1;
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  char* const patch = lds;                                // [2][C3_PATCH_BYTES]
-  char* const ring = lds + 2 * C3_PATCH_BYTES;            // [RB][WSTEP]
+  char* const patch = lds;                                // [PB][C3_PATCH_BYTES]
+  char* const ring = lds + PB * C3_PATCH_BYTES;           // [RB][WSTEP]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int NCH = p.Cin >> 5, S = 9 * NCH;
+  // Every wave requests a quarter of both the filters and the patch.  (Tried: waves 0, 1 requesting only filters and waves 2, 3 only the
+  // patch, so that a filter wait never stands behind an HBM-latency patch piece in the in-order vmcnt queue -- 3-10 % SLOWER on every layer:
+  // issuing an LDS-DMA costs its wave 60-180 cycles, and two waves carrying all of one kind become the step's critical path.)
+  constexpr int NSH = 4;                                              // waves sharing the DMA duty
+  const int role = wave;
+  constexpr int PPW = 24 / NSH, FPW = (CT / 16) / NSH;                // patch pieces per wave and chunk, filter pieces per wave and step
 
   // ---- tile: ct-major numbering, so the workgroups running together share one filter slab in L2; XCD-contiguous ----
   const int nsp = p.N * p.TBY * p.TBX;
@@ -81,130 +83,174 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16(const C3Args p) {
   sp /= p.TBX;
   const int by = sp % p.TBY, n = sp / p.TBY;
 
-  // ---- patch staging: instruction (4 j + wave), j < 6, fills 64 consecutive 16-byte slots; slot i = pixel i >> 2,
-  //      piece (i & 3) ^ swz(pixel): the swizzle sits on the SOURCE address, the LDS image stays lane-linear -----------
+  // ---- patch staging: instruction (2 j + role), j < 12, fills 64 consecutive 16-byte slots; slot i = image pixel i >> 2 (rows of
+  //      20: 18 + 2 unused), piece (i & 3) ^ swz(pixel): the swizzle sits on the SOURCE address, the LDS image stays lane-linear.
+  //      The 12 source offsets are recomputed per chunk (patch waves only) instead of living in 12 registers across the loop -------
   const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)kOob, 0x00020000);
-  unsigned pv[C3_PDMA];
-  {
+  auto patch_dma = [&](unsigned soff, int buf, int j0, int j1, bool live) {   // this wave's pieces j0 .. j1-1 of a chunk
+    int l = lane;
+    asm volatile("" : "+v"(l));                                      // (opaque: keeps hipcc from hoisting the offsets out of the chunk loop)
     const int iy0 = 16 * by - 1, ix0 = 16 * bx - 1;
 #pragma unroll
-    for (int j = 0; j < C3_PDMA; ++j) {
-      const int i = (4 * j + wave) * 64 + lane;
+    for (int j = j0; j < j1; ++j) {
+      const int i = (NSH * j + role) * 64 + l;
       const int pix = i >> 2, kg = (i & 3) ^ (((pix >> 2) & 1) << 1);
-      const int py = (pix * 3641) >> 16, px = pix - py * C3_PW;            // pix / 18 for pix < 1024
+      const int py = (pix * 3277) >> 16, px = pix - py * C3_PITCH;         // pix / 20 for pix < 1024
       const int iy = iy0 + py, ix = ix0 + px;
-      const bool ok = pix < C3_PW * C3_PW && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      pv[j] = ok ? (unsigned)((((n * p.H + iy) * p.W + ix) * p.x_cs + kg * 8) * 2) : kOob;
+      const bool ok = live && px < C3_PW && py < C3_PW && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const unsigned voff = ok ? (unsigned)((((n * p.H + iy) * p.W + ix) * p.x_cs + kg * 8) * 2) : kOob;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rsx, (__attribute__((address_space(3))) void*)(patch + buf * C3_PATCH_BYTES + (NSH * j + role) * 1024), 16, voff, soff, 0, 0);
     }
-  }
-  auto patch_dma = [&](unsigned voff, unsigned soff, int buf, int j) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(
-        rsx, (__attribute__((address_space(3))) void*)(patch + buf * C3_PATCH_BYTES + (4 * j + wave) * 1024), 16, voff, soff, 0, 0);
   };
 
-  // ---- filter ring: the image of step s is WSTEP contiguous bytes at (ct * S + s) * WSTEP; wave w copies pieces w, w+4;
+  // ---- filter ring: the image of step s is WSTEP contiguous bytes at (ct * S + s) * WSTEP; filter wave f copies pieces f, f+2, ..;
   //      steps past the end read past num_records and arrive as zeros in a slot nobody reads any more ------------------
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wp), 0, (int)p.wbytes, 0x00020000);
   const unsigned w_lane = (unsigned)(lane * 16);
   const unsigned w_tile = (unsigned)(ct * S) * (unsigned)WSTEP;
   auto ring_dma = [&](int step, int slot) {
 #pragma unroll
-    for (int i = 0; i < NBP; ++i)
+    for (int i = 0; i < FPW; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          rsw, (__attribute__((address_space(3))) void*)(ring + slot * WSTEP + (wave + 4 * i) * 1024), 16, w_lane,
-          w_tile + (unsigned)step * (unsigned)WSTEP + (unsigned)((wave + 4 * i) * 1024), 0, 0);
+          rsw, (__attribute__((address_space(3))) void*)(ring + slot * WSTEP + (role + NSH * i) * 1024), 16, w_lane,
+          w_tile + (unsigned)step * (unsigned)WSTEP + (unsigned)((role + NSH * i) * 1024), 0, 0);
   };
 
-  // ---- fragment read addresses (bytes).  x: pixel row r of the wave's MT + 2 patch rows, tap column kw ----------------
+  // ---- fragment read addresses (bytes).  Image pixel (py, px) sits at slot (py * 20 + px) * 4 + (kg ^ swz), swz = 2 * (((py * 20 + px) >> 2) & 1)
+  //      = 2 * ((py & 1) ^ ((px >> 2) & 1)) because a row is 5 quads: the address of (row, tap column kw) is a per-lane term that depends on
+  //      kw and the row's PARITY only (6 registers) plus row * 1280 as an instruction immediate (the wave's first row is even) ------------
   const int col = lane & 15, kgl = lane >> 4;
-  int xa[MT + 2][3];
+  int xa[3][2];
 #pragma unroll
-  for (int r = 0; r < MT + 2; ++r)
+  for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-      const int pix = (wm * MT + r) * C3_PW + kw + col;
-      xa[r][kw] = (pix * 4 + (kgl ^ (((pix >> 2) & 1) << 1))) * 16;
+    for (int par = 0; par < 2; ++par) {
+      const int px = kw + col;
+      xa[kw][par] = wm * MT * (C3_PITCH * 64) + px * 64 + ((kgl ^ ((par ^ ((px >> 2) & 1)) << 1)) << 4);
     }
-  const int wa = 2 * C3_PATCH_BYTES + wn * 4096 + lane * 16;          // + slot * WSTEP + nt * 1024
+  const int wa = PB * C3_PATCH_BYTES + wn * 4096 + lane * 16;          // + slot * WSTEP + nt * 1024
 
+  // ---- output addressing (epilogue; the residual of the 64-channel / two-buffer variant is requested up front) ------------
+  // acc[nt][mt][j] = channel ct*CT + wn*64 + nt*16 + 4*(lane>>4) + j of pixel (row wm*MT + mt, column lane&15)
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)kOob, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, (int)kOob, 0x00020000);
+  const int co0 = ct * CT + wn * 64 + 4 * kgl;
+  const int ox = 16 * bx + col, oy0 = 16 * by + wm * MT;
+  const unsigned pixel0 = (unsigned)((n * p.H + oy0) * p.W + ox);
+  auto out_ok = [&](int mt) { return ox < p.W && oy0 + mt < p.H; };
+  u32x2 rv[Geo::RES_EARLY ? MT : 1][NT];
+  auto load_res = [&](int mt, u32x2 (&dst)[NT]) {
+    const unsigned ro = out_ok(mt) ? ((pixel0 + (unsigned)(mt * p.W)) * (unsigned)p.res_cs + (unsigned)co0) * 2u : kOob;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) dst[nt] = __builtin_amdgcn_raw_buffer_load_b64(rsr, ro, (unsigned)(nt * 32), 0);
+  };
+
+  int mt_live = p.H - (16 * by + wm * MT);                            // pixel rows of this wave inside the image (wave-uniform)
+  mt_live = mt_live < 0 ? 0 : (mt_live > MT ? MT : mt_live);
   f32x4 acc[NT][MT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- prologue: filters of steps 0 .. D-1, patch chunk 0 -----------------------------------------------------------
+  // ---- prologue: filters of steps 0 .. D-1, patch chunk 0 (and the residual: one HBM round trip covers both) ----------------
 #pragma unroll
   for (int s = 0; s < D; ++s) ring_dma(s, s);
+  patch_dma(0, 0, 0, PPW, true);
+  if constexpr (Geo::RES_EARLY) {
+    if (p.res) {
 #pragma unroll
-  for (int j = 0; j < C3_PDMA; ++j) patch_dma(pv[j], 0, 0, j);
+      for (int mt = 0; mt < MT; ++mt) load_res(mt, rv[mt]);
+    }
+  }
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
-  // One step = one filter tap of one 32-channel chunk: MT x NT MFMAs per wave.  Issue order inside a step: the filter
-  // pieces of step s + D, then (taps 0..5) one sixth of the NEXT chunk's patch; loads retire in order, so the wait at the
-  // step's end -- vmcnt(pieces issued after the filters of step s + 1) -- names exactly those filters and, after tap 8,
-  // the whole next patch chunk; everything younger stays in flight across the barrier.
+  // One step = one filter tap of one 32-channel chunk: MT x NT MFMAs per wave.  Issue order inside a step: the filter pieces of step
+  // s + D, then (two-buffer variant, taps 0..5) one sixth of the NEXT chunk's patch; loads retire in order, so the wait at the step's
+  // end -- vmcnt(pieces issued after the filters of step s + 1) -- names exactly those filters and, after tap 8, the whole next patch
+  // chunk; everything younger stays in flight across the barrier.
   int slot = 0;                                                      // ring slot of the current step
-  auto step = [&](auto tc, const int s, const int pbuf, const unsigned psoff, const bool pnext) {
+  auto step = [&](auto tc, auto livec, const int s, const int pbuf, const unsigned psoff, const bool pnext) {
     constexpr int t = decltype(tc)::value, kh = t / 3, kw = t % 3;
     {
       int ns = slot + D;
       ns = ns >= RB ? ns - RB : ns;
       ring_dma(s + D, ns);
     }
-    if constexpr (t < C3_PDMA) patch_dma(pnext ? pv[t] : kOob, psoff, pbuf ^ 1, t);
-    bf16x8 wf[NT], xf[MT];
-    const char* wb = lds + wa + slot * WSTEP;
+    if constexpr (PB == 2 && t < PPW) patch_dma(psoff, pbuf ^ 1, t, t + 1, pnext);   // one piece per step, taps 0 .. 5 (zeros past the last chunk)
+    constexpr int LIVE = decltype(livec)::value;                    // pixel rows of this wave that take part (the rest lie below the image)
+    if constexpr (LIVE > 0) {
+      bf16x8 wf[NT], xf[LIVE];
+      const char* wb = lds + wa + slot * WSTEP;
+      const char* pb = patch + pbuf * C3_PATCH_BYTES;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wf[nt] = *reinterpret_cast<const bf16x8*>(wb + nt * 1024);
-    const char* pb = patch + pbuf * C3_PATCH_BYTES;
+      for (int nt = 0; nt < NT; ++nt) wf[nt] = *reinterpret_cast<const bf16x8*>(wb + nt * 1024);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) xf[mt] = *reinterpret_cast<const bf16x8*>(pb + xa[mt + kh][kw]);
+      for (int mt = 0; mt < LIVE; ++mt)
+        xf[mt] = *reinterpret_cast<const bf16x8*>(pb + xa[kw][(mt + kh) & 1] + (mt + kh) * (C3_PITCH * 64));
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < LIVE; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt)
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+    }
     slot = slot + 1 == RB ? 0 : slot + 1;
-    constexpr int cnt = c3_wait_count(t, D, NBP);
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(cnt) : "memory");
+    // pieces this wave has issued AFTER the filters of step s + 1 (which left first thing in step s + 1 - D): FPW per later step, one
+    // patch piece in each of the D steps whose tap is < 6; after tap 8 that also covers the whole next patch chunk
+    constexpr int cnt = [] {
+      int c = (D - 1) * FPW;
+      if (PB == 2)
+        for (int u = 0; u < D; ++u) c += ((t - u + 9) % 9) < PPW ? 1 : 0;
+      return c;
+    }();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(cnt) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
   using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
   using T3 = std::integral_constant<int, 3>; using T4 = std::integral_constant<int, 4>; using T5 = std::integral_constant<int, 5>;
   using T6 = std::integral_constant<int, 6>; using T7 = std::integral_constant<int, 7>; using T8 = std::integral_constant<int, 8>;
-  for (int c = 0; c < NCH; ++c) {
-    const int pbuf = c & 1, s0 = 9 * c;
-    const unsigned psoff = (unsigned)((c + 1) * 64);                 // next chunk: + 32 channels
-    const bool pnext = c + 1 < NCH;
-    step(T0{}, s0 + 0, pbuf, psoff, pnext); step(T1{}, s0 + 1, pbuf, psoff, pnext); step(T2{}, s0 + 2, pbuf, psoff, pnext);
-    step(T3{}, s0 + 3, pbuf, psoff, pnext); step(T4{}, s0 + 4, pbuf, psoff, pnext); step(T5{}, s0 + 5, pbuf, psoff, pnext);
-    step(T6{}, s0 + 6, pbuf, psoff, pnext); step(T7{}, s0 + 7, pbuf, psoff, pnext); step(T8{}, s0 + 8, pbuf, psoff, pnext);
+  auto kloop = [&](auto lv) {
+    for (int c = 0; c < NCH; ++c) {
+      const int pbuf = PB == 2 ? (c & 1) : 0, s0 = 9 * c;
+      if (PB == 1 && c > 0) {                                        // every wave has left the previous chunk (barrier): refill in place
+        patch_dma((unsigned)(c * 64), 0, 0, PPW, true);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+      const unsigned psoff = (unsigned)((c + 1) * 64);               // next chunk: + 32 channels
+      const bool pnext = c + 1 < NCH;
+      step(T0{}, lv, s0 + 0, pbuf, psoff, pnext); step(T1{}, lv, s0 + 1, pbuf, psoff, pnext); step(T2{}, lv, s0 + 2, pbuf, psoff, pnext);
+      step(T3{}, lv, s0 + 3, pbuf, psoff, pnext); step(T4{}, lv, s0 + 4, pbuf, psoff, pnext); step(T5{}, lv, s0 + 5, pbuf, psoff, pnext);
+      step(T6{}, lv, s0 + 6, pbuf, psoff, pnext); step(T7{}, lv, s0 + 7, pbuf, psoff, pnext); step(T8{}, lv, s0 + 8, pbuf, psoff, pnext);
+    }
+  };
+  // Bottom-edge blocks: a wave's pixel rows below the image are skipped in quarters of its MT rows (wave-uniform choice of a loop
+  // specialised at compile time; per-row branches inside one loop cost hipcc 245 spilled registers).  With two to four workgroups per
+  // CU the matrix-pipe and LDS cycles those rows would have burnt go to the co-resident workgroups (H = 57: 7 of 64 rows, H = 113:
+  // 15 of 128).  Skipped rows keep their zero accumulators and are never stored.
+  constexpr int QM = MT / 4;
+  switch ((mt_live + QM - 1) / QM) {
+    case 0: kloop(std::integral_constant<int, 0>{}); break;
+    case 1: kloop(std::integral_constant<int, QM>{}); break;
+    case 2: kloop(std::integral_constant<int, 2 * QM>{}); break;
+    case 3: kloop(std::integral_constant<int, 3 * QM>{}); break;
+    default: kloop(std::integral_constant<int, MT>{}); break;
   }
 
-  // ---- epilogue: acc[nt][mt][j] = channel ct*CT + wn*64 + nt*16 + 4*(lane>>4) + j of pixel (row wm*MT + mt, column lane&15) ----
-  const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)kOob, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, (int)kOob, 0x00020000);
-  const int co0 = ct * CT + wn * 64 + 4 * kgl;
-  const int ox = 16 * bx + col, oy0 = 16 * by + wm * MT;
-  const bool xok = ox < p.W;
+  // ---- epilogue: folded BN, residual, ReLU, bf16x4 stores --------------------------------------------------------------------
   f32x4 sc[NT], sh[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     sc[nt] = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + co0 + nt * 16) : f32x4{1.f, 1.f, 1.f, 1.f};
     sh[nt] = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + co0 + nt * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const int oy = oy0 + mt;
-    const bool ok = xok && oy < p.H;
-    const unsigned pixel = (unsigned)((n * p.H + oy) * p.W + ox);
-    const unsigned yo = ok ? (pixel * (unsigned)p.y_cs + (unsigned)co0) * 2u : kOob;
-    const unsigned ro = ok ? (pixel * (unsigned)p.res_cs + (unsigned)co0) * 2u : kOob;
-    u32x2 rv[NT];
-    if (p.res) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) rv[nt] = __builtin_amdgcn_raw_buffer_load_b64(rsr, ro, (unsigned)(nt * 32), 0);
+    const unsigned yo = out_ok(mt) ? ((pixel0 + (unsigned)(mt * p.W)) * (unsigned)p.y_cs + (unsigned)co0) * 2u : kOob;
+    u32x2 (&rr)[NT] = rv[Geo::RES_EARLY ? mt : 0];
+    if constexpr (!Geo::RES_EARLY) {
+      if (p.res) load_res(mt, rr);
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -212,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16(const C3Args p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = fmaf(acc[nt][mt][j], sc[nt][j], sh[nt][j]);
       if (p.res) {
-        const bf16x4 r4 = __builtin_bit_cast(bf16x4, rv[nt]);
+        const bf16x4 r4 = __builtin_bit_cast(bf16x4, rr[nt]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] += (float)r4[j];
       }
@@ -300,13 +346,19 @@ extern "C" int bevf_conv3x3_bf16(const bevf_conv_desc* d, void* stream) {
   const long long ntiles = (long long)d->N * a.TBY * a.TBX * a.nct;
   BEVF_REQUIRE(ntiles < (1ll << 31), "conv3x3_bf16: too many tiles");
   hipStream_t st = static_cast<hipStream_t>(stream);
+  // tile: 0 = auto, 1 = two patch buffers (2 workgroups per CU), 2 = one (4 per CU; 64-channel tiles only).  Auto takes the single
+  // buffer for 64-channel tiles with Cin >= 128 (tools/conv3x3_bench.py: head 168 -> 155 us; layer1, two chunks only, is a tie)
+  constexpr int lds128 = C3Geo<128, 2>::LDS_BYTES, lds64 = C3Geo<64, 2>::LDS_BYTES, lds64s = C3Geo<64, 1>::LDS_BYTES;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16<64>), hipFuncAttributeMaxDynamicSharedMemorySize, C3Geo<64>::LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16<128>), hipFuncAttributeMaxDynamicSharedMemorySize, C3Geo<128>::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16<64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds64);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16<128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds128);
     attr_done = true;
   }
-  if (CT == 128) hipLaunchKernelGGL((conv3x3_bf16<128>), dim3((unsigned)ntiles), dim3(256), C3Geo<128>::LDS_BYTES, st, a);
-  else hipLaunchKernelGGL((conv3x3_bf16<64>), dim3((unsigned)ntiles), dim3(256), C3Geo<64>::LDS_BYTES, st, a);
+  const bool pb1 = CT == 64 && (d->tile == 2 || (d->tile == 0 && d->Cin >= 128));
+  const dim3 grid((unsigned)ntiles), block(256);
+  if (CT == 128) hipLaunchKernelGGL((conv3x3_bf16<128, 2>), grid, block, lds128, st, a);
+  else if (pb1) hipLaunchKernelGGL((conv3x3_bf16<64, 1>), grid, block, lds64s, st, a);
+  else hipLaunchKernelGGL((conv3x3_bf16<64, 2>), grid, block, lds64, st, a);
   return bevf_check_launch("bevf_conv3x3_bf16");
 }

@@ -49,7 +49,7 @@ struct RadarArgs {
 constexpr int RCH = 32;   // points per chunk
 
 __global__ __launch_bounds__(256) void radar_mlp_max(const RadarArgs a) {
-  extern __shared__ float sm[];
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   const int cmax_a = a.c[0] > a.c[2] ? a.c[0] : a.c[2];
   float* bufA = sm;                                               // [RCH][max(Cin, c0, c2)]
   float* bufB = sm + RCH * (cmax_a > a.Cin ? cmax_a : a.Cin);     // [RCH][max(Cin, c1)]
@@ -71,7 +71,29 @@ __global__ __launch_bounds__(256) void radar_mlp_max(const RadarArgs a) {
       float acc[RCH];
 #pragma unroll
       for (int q = 0; q < RCH; ++q) acc[q] = 0.f;
-      for (int k = 0; k < cin; ++k) {
+      // eight k at a time: the eight weight loads are independent (one k per iteration left every iteration waiting out an L2 round
+      // trip: 272 us for 55 MFLOP at B = 8) and a point's eight inputs are two 16-byte LDS reads; each accumulator still sees its
+      // products in ascending k -> the same bits as the one-k loop
+      int k = 0;
+      if ((cin & 3) == 0) {
+        for (; k + 8 <= cin; k += 8) {
+          float wv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) wv[j] = a.w[l][(size_t)(k + j) * co + ch];
+#pragma unroll
+          for (int q = 0; q < RCH; ++q) {
+            const int pt = pl + q * lanes;
+            if (q * lanes < RCH && pt < np) {
+              const f32x4 i0 = *reinterpret_cast<const f32x4*>(in + pt * cin + k), i1 = *reinterpret_cast<const f32x4*>(in + pt * cin + k + 4);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[q] = fmaf(i0[j], wv[j], acc[q]);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[q] = fmaf(i1[j], wv[4 + j], acc[q]);
+            }
+          }
+        }
+      }
+      for (; k < cin; ++k) {
         const float wv = a.w[l][(size_t)k * co + ch];
 #pragma unroll
         for (int q = 0; q < RCH; ++q) {

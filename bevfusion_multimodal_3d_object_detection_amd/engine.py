@@ -93,12 +93,13 @@ def pack_conv(conv, bn=None, relu: bool = True, split_ok: bool = True, wino_ok: 
 
 def _finish_pack(packed, scale, shift, cin, cout, k, stride, pad, relu, split_ok=True, wino_ok=True) -> PackedConv:
     """OHWI filter -> what the active conv mode's kernel reads."""
+    bf16_model = packed.dtype == torch.bfloat16          # (the f32x3 planes below are bf16 too, but belong to an fp32 model)
     if packed.dtype == torch.float32 and cin % 32 == 0:
         if _CONV_MODE in ("wino", "wino_x3") and wino_ok and (k, stride, pad) == (3, 1, 1):
             return PackedConv(L.wino_filter_transform(packed, cout, cin), scale, shift, cin, cout, k, stride, pad, relu, wino=True)
         if _CONV_MODE in ("f32x3", "wino_x3") and split_ok:
             packed = L.split_weights_f32x3(packed)
-    if (BF16_CONV3X3 and packed.dtype == torch.bfloat16 and (k, stride, pad) == (3, 1, 1) and cin % 32 == 0 and cout % 64 == 0
+    if (BF16_CONV3X3 and bf16_model and (k, stride, pad) == (3, 1, 1) and cin % 32 == 0 and cout % 64 == 0
             and wino_ok):
         return PackedConv(L.conv3x3_pack_bf16(packed, cout, cin), scale, shift, cin, cout, k, stride, pad, relu, c3=True)
     return PackedConv(packed, scale, shift, cin, cout, k, stride, pad, relu)

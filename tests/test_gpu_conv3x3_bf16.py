@@ -26,7 +26,7 @@ def nhwc(t, cs=None):
     return v.reshape(-1).to(BF).cuda()
 
 
-def run(x, w, scale, shift, res, relu, x_cs=None, y_cs=None, res_cs=None):
+def run(x, w, scale, shift, res, relu, x_cs=None, y_cs=None, res_cs=None, tile=0):
     N, cin, H, W = x.shape
     cout = w.shape[0]
     x_cs, y_cs = x_cs or cin, y_cs or cout
@@ -35,7 +35,7 @@ def run(x, w, scale, shift, res, relu, x_cs=None, y_cs=None, res_cs=None):
     y = torch.full((N * H * W * y_cs,), 55.0, dtype=BF, device="cuda")
     L.conv3x3_bf16(nhwc(x, x_cs), wp, None if scale is None else scale.cuda(), None if shift is None else shift.cuda(), y,
                    N=N, H=H, W=W, Cin=cin, x_cs=x_cs, Cout=cout, y_cs=y_cs, relu=relu,
-                   res=None if res is None else nhwc(res, res_cs), res_cs=res_cs)
+                   res=None if res is None else nhwc(res, res_cs), res_cs=res_cs, tile=tile)
     torch.cuda.synchronize()
     full = y.float().view(N, H, W, y_cs).cpu()
     if y_cs > cout:
@@ -69,6 +69,8 @@ def test_conv3x3_bf16_against_fp64(gpu, N, H, W, cin, cout, res, relu, x_cs, y_c
         ref = F.relu(ref)
     got = run(x, w, scale, shift, rs, relu, x_cs, y_cs)
     assert rel_err(got, ref.float()) <= 4e-3                  # exact products, fp32 accumulate, one bf16 rounding at the store
+    for tile in (1, 2):                                       # the buffering variants run the same arithmetic in the same order
+        assert torch.equal(run(x, w, scale, shift, rs, relu, x_cs, y_cs, tile=tile), got), tile
     # the kernel it replaces on the same operands: both round the same fp32-level value to bf16
     y2 = torch.zeros(N * H * W * cout, dtype=BF, device=gpu)
     L.conv2d_nhwc(nhwc(x), w.permute(0, 2, 3, 1).contiguous().view(-1).to(BF).cuda(), scale.cuda(), shift.cuda(), y2, N=N, H=H, W=W,
@@ -89,8 +91,9 @@ def test_conv3x3_bf16_exact_on_integer_data(gpu, N, H, W, cin, cout):
     w = torch.randint(-1, 2, (cout, cin, 3, 3), generator=g).float()
     ref = F.conv2d(x.double(), w.double(), None, 1, 1)
     assert float(ref.abs().max()) <= 256                      # integers up to 256 are bf16 numbers
-    got = run(x, w, None, None, None, False)
-    assert torch.equal(got.double(), ref)
+    for tile in (1, 2):                                       # two patch buffers / one (the high-occupancy variant of 64-channel tiles)
+        got = run(x, w, None, None, None, False, tile=tile)
+        assert torch.equal(got.double(), ref), tile
 
 
 def test_conv3x3_bf16_refuses_what_it_cannot_do(gpu):

@@ -37,14 +37,16 @@ for name in names:
     def old():
         L.conv2d_nhwc(x, w, sc, sh, y0, KH=3, KW=3, stride=1, pad=1, **kw)
 
-    def new():
-        L.conv3x3_bf16(x, wp, sc, sh, y1, **kw)
-    t = {"old": [], "new": []}
+    variants = {"old": old}
+    for tile, label in ((0, "auto"), (1, "pb2"), (2, "pb1")):
+        variants[label] = (lambda tl: (lambda: L.conv3x3_bf16(x, wp, sc, sh, y1, tile=tl, **kw)))(tile)
+    t = {k: [] for k in variants}
     for _ in range(2):
-        old(); new()
+        for fn in variants.values():
+            fn()
     torch.cuda.synchronize()
     for _ in range(rounds):
-        for key, fn in (("old", old), ("new", new)):
+        for key, fn in variants.items():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
@@ -53,5 +55,6 @@ for name in names:
             t[key].append(e0.elapsed_time(e1) / 5)
     flops = 2.0 * N * H * W * Cout * 9 * Cin
     diff = float((y0.float() - y1.float()).abs().max() / y0.float().abs().max())
-    f = lambda v: f"{sorted(v)[len(v) // 2] * 1e3:8.1f} us {flops / sorted(v)[len(v) // 2] / 1e9:7.1f} TF (min {min(v) * 1e3:7.1f})"
-    print(f"{name:11s} {flops / 1e9:7.1f} GF  igemm {f(t['old'])}   conv3x3 {f(t['new'])}   max rel diff {diff:.1e}", flush=True)
+    med = lambda v: sorted(v)[len(v) // 2]
+    print(f"{name:11s} {flops / 1e9:7.1f} GF  " + "  ".join(f"{k} {med(v) * 1e3:6.1f}us {flops / med(v) / 1e9:6.0f}TF" for k, v in t.items())
+          + f"  max rel diff {diff:.1e}", flush=True)
