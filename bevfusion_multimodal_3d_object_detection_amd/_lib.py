@@ -95,6 +95,7 @@ SIGNATURES = {
     "bevf_pointnet_front_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 11),
     "bevf_pointnet_front_pack_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 2 + [C.c_void_p]),
     "bevf_group_max_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 3 + [C.c_void_p]),
+    "bevf_vfe_smallk_max_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_radar_mlp_max_f32": (C.c_int, [C.POINTER(RadarDesc), C.c_void_p]),
     "bevf_linear_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p]),
     "bevf_cam_mean_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
@@ -428,6 +429,14 @@ def pointnet_front(x, w1, s1, b1, w2f, s2, b2, w3f, s3, b3, y, M: int, K: int):
         raise BevfError("pointnet_front: buffer sizes do not match M, K and the 64/128/256 widths")
     _check(lib().bevf_pointnet_front_f32(_pc(x), M, K, _pc(w1), _pc(s1), _pc(b1), _pc(w2f), _pc(s2), _pc(b2), _pc(w3f), _pc(s3),
                                          _pc(b3), _p(y), _stream()), "bevf_pointnet_front_f32")
+
+
+def vfe_smallk_max(x, w, scale, shift, y, G: int, P: int, K: int, Cout: int) -> None:
+    """VFELayer for K <= 16 in one pass: pointwise linear + folded BN + ReLU + max over the P rows of each group."""
+    if x.numel() < G * P * K or w.numel() != Cout * K or y.numel() < G * Cout:
+        raise BevfError("vfe_smallk_max: buffer sizes do not match G, P, K, Cout")
+    _check(lib().bevf_vfe_smallk_max_f32(_pc(x), _pc(w), _pc(scale), _pc(shift), _p(y), G, P, K, Cout, _stream()),
+           "bevf_vfe_smallk_max_f32")
 
 
 def group_max(x, y, G: int, P: int, Cc: int):

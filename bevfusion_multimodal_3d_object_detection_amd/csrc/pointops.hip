@@ -229,7 +229,61 @@ __global__ __launch_bounds__(256) void group_max(const float* __restrict__ x, fl
   }
 }
 
+// ---- VFELayer in one pass (K <= 16): y[g][n] = max_p relu((sum_k x[g][p][k] w[n][k]) * scale[n] + shift[n]) -------------------
+// ref src/encoders.py:431-455 (Linear -> BN1d -> ReLU -> max over the P points of a voxel; zero-padded points take part, as there).
+// A wave owns a voxel, a lane a channel (its K weights and scale / shift live in registers); the voxel's P x K inputs are wave-wide
+// broadcast loads.  Same fma chain, same relu and the same fmaxf as pointwise_smallk + group_max -> the same bits, without the
+// [G][P][Cout] intermediate (164 MB written and read back at B = 8, 2500 pillars x 32 points x 64 channels).
+template <int K>
+__global__ __launch_bounds__(256) void vfe_smallk_max(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, float* __restrict__ y, int G, int P, int Cout) {
+  constexpr int PC = 64 / K;                                      // points per coalesced 64-lane load
+  const int lane = threadIdx.x & 63;
+  const long long wave = (blockIdx.x * 256ll + threadIdx.x) >> 6, nwaves = (long long)gridDim.x * 4;
+  for (int c0 = 0; c0 < Cout; c0 += 64) {
+    const int n = c0 + lane;
+    const bool live = n < Cout;
+    float wv[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) wv[k] = live ? w[(size_t)n * K + k] : 0.f;
+    const float sc = (live && scale) ? scale[n] : 1.f, sh = (live && shift) ? shift[n] : 0.f;
+    for (long long g = wave; g < G; g += nwaves) {
+      const float* src = x + (size_t)g * P * K;
+      float m = 0.f;
+      for (int p0 = 0; p0 < P; p0 += PC) {                        // lane l holds element l of this run of points; a point's inputs
+        const int np = P - p0 < PC ? P - p0 : PC;                 // reach every lane as scalar operands (v_readlane, uniform index)
+        const int xv = lane < np * K ? __float_as_int(src[p0 * K + lane]) : 0;
+        for (int pp = 0; pp < np; ++pp) {
+          float acc = 0.f;
+#pragma unroll
+          for (int k = 0; k < K; ++k) acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(xv, pp * K + k)), wv[k], acc);
+          float v = fmaf(acc, sc, sh);
+          v = !(v > 0.f) ? 0.f : v;
+          m = (p0 + pp) == 0 ? v : fmaxf(m, v);
+        }
+      }
+      if (live) y[(size_t)g * Cout + n] = m;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int bevf_vfe_smallk_max_f32(const float* x, const float* w, const float* scale, const float* shift, float* y, int G, int P,
+                                       int K, int Cout, void* stream) {
+  BEVF_REQUIRE(x && w && y, "vfe: null pointer");
+  BEVF_REQUIRE(G > 0 && P > 0 && K > 0 && K <= 16 && Cout > 0, "vfe: need G, P, Cout > 0 and 0 < K <= 16 (K=%d)", K);
+  const long long blocks = ((long long)G + 3) / 4;
+  const dim3 grid((unsigned)(blocks > 8192 ? 8192 : blocks));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define BEVF_VFE(Kv) case Kv: hipLaunchKernelGGL(vfe_smallk_max<Kv>, grid, dim3(256), 0, st, x, w, scale, shift, y, G, P, Cout); break;
+  switch (K) {
+    BEVF_VFE(1) BEVF_VFE(2) BEVF_VFE(3) BEVF_VFE(4) BEVF_VFE(5) BEVF_VFE(6) BEVF_VFE(7) BEVF_VFE(8)
+    BEVF_VFE(9) BEVF_VFE(10) BEVF_VFE(11) BEVF_VFE(12) BEVF_VFE(13) BEVF_VFE(14) BEVF_VFE(15) BEVF_VFE(16)
+  }
+#undef BEVF_VFE
+  return bevf_check_launch("bevf_vfe_smallk_max_f32");
+}
 
 extern "C" int bevf_group_max_f32(const float* x, float* y, int G, int P, int C, void* stream) {
   BEVF_REQUIRE(x && y && G > 0 && P > 0 && C > 0 && C % 4 == 0, "group_max: bad arguments (C=%d)", C);

@@ -7,12 +7,15 @@
 //   * a voxel keeps its first max_points points in input order, zero padded.
 // Pipeline (all frames of the batch at once):
 //   keys  (frame, cell, point index) packed in 64 bits                          -- one thread per point
-//   sort  per frame, one workgroup: stable LSD radix sort on the cell bits, 8 bits a pass; an element's rank inside
-//         its wave comes from 8 ballots (the lanes holding the same digit) + a popcount, the waves' counts are
-//         prefix-summed per digit in LDS                                          -- groups cells, keeps point order
+//   sort  stable LSD radix sort on the cell bits, 8 bits a pass, MANY workgroups per frame (round 3; rounds 1-2 walked a frame with one
+//         workgroup = 8 of 256 CUs at B = 8): per pass  vox_hist  (digit histogram of every 1024-key tile)  ->  vox_offsets  (per frame:
+//         where each tile's keys of each digit go: digits below + same digit in earlier tiles)  ->  vox_scatter  (a key's rank among
+//         its wave's keys of the same digit from 8 ballots + a popcount, the tile's waves / rounds chained through LDS counters) --
+//         groups cells, keeps point order
 //   heads a sorted position is a segment head when its (frame,cell) differs from its predecessor; the head
 //         marks its first point in a per-point flag array                         -- one thread per position
-//   scan  per-frame exclusive scan of the flags in POINT order = voxel id in first-appearance order
+//   scan  per-frame exclusive scan of the flags in POINT order = voxel id in first-appearance order: vox_flagcount (heads per
+//         1024-point tile) -> vox_vid (a tile adds up the counts of the tiles before it, then scans its own flags)
 //   fill  one wave per voxel copies its first max_points points with 16-byte-free, coalesced row copies
 #include "common.h"
 
@@ -45,82 +48,92 @@ __global__ __launch_bounds__(256) void vox_keys(const VoxArgs a, unsigned long l
   keys[i] = ((unsigned long long)b << 52) | (cell << 20) | (unsigned long long)n;
 }
 
-// Stable LSD radix sort of one frame's keys by cell (bits 20..51), 8 bits per pass, `passes` passes; the point index in
-// the low 20 bits is already ascending in the input, and a stable sort keeps it so.  One workgroup of 1024 threads
-// (16 waves) per frame walks the frame in tiles of 1024 keys IN ORDER:
-//   * rank inside the wave: 8 ballots narrow the lane mask down to the lanes holding the same digit; the number of
-//     those below the lane is its rank, the lowest of them publishes the count for (wave, digit);
-//   * 256 threads turn the 16 per-wave counts of each digit into offsets and advance the digit's running base;
-//   * every key is written to base[digit] + earlier waves of the tile + rank in the wave.
-// Ends with the sorted keys in `a` when `passes` is even, in `b` when odd.
-__global__ __launch_bounds__(1024) void vox_sort(unsigned long long* __restrict__ a, unsigned long long* __restrict__ b, int N,
-                                                  int passes) {
-  __shared__ int hist[4][256];
-  __shared__ int base[256];
-  __shared__ int wcnt[16][256];
-  __shared__ int wtot[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  unsigned long long* src = a + (size_t)blockIdx.x * N;
-  unsigned long long* dst = b + (size_t)blockIdx.x * N;
-  hist[tid >> 8][tid & 255] = 0;
+// ---- stable LSD radix sort of every frame's keys by cell (bits 20..51), 8 bits per pass --------------------------------------
+// The point index in the low 20 bits is ascending in the input and a stable sort keeps it so.  A tile = 1024 consecutive keys
+// of one frame, one 256-thread workgroup (4 waves x 4 rounds of 64 keys, in order).
+constexpr int VT = 1024;                                         // keys per tile
+
+// hist[frame][tile][digit] = keys of the tile whose digit q is `digit`
+__global__ __launch_bounds__(256) void vox_hist(const unsigned long long* __restrict__ keys, int* __restrict__ hist, int N, int T,
+                                                  int q) {
+  __shared__ int h[256];
+  const int tid = threadIdx.x, tile = blockIdx.x % T, b = blockIdx.x / T;
+  h[tid] = 0;
   __syncthreads();
-  for (int i = tid; i < N; i += 1024) {
-    const unsigned cell = (unsigned)(src[i] >> 20);
-    for (int q = 0; q < passes; ++q) atomicAdd(&hist[q][(cell >> (8 * q)) & 255], 1);
+  const unsigned long long* src = keys + (size_t)b * N;
+#pragma unroll
+  for (int r = 0; r < VT / 256; ++r) {
+    const int i = tile * VT + r * 256 + tid;
+    if (i < N) atomicAdd(&h[((unsigned)(src[i] >> 20) >> (8 * q)) & 255u], 1);
   }
   __syncthreads();
-  for (int q = 0; q < passes; ++q) {
-    if (tid < 256) {                                            // exclusive scan of the 256 digit counts -> base
-      const int c = hist[q][tid];
-      int incl = c;
+  hist[((size_t)b * T + tile) * 256 + tid] = h[tid];
+}
+
+// per frame (one workgroup, thread = digit): hist -> the position of each tile's first key of each digit
+__global__ __launch_bounds__(256) void vox_offsets(int* __restrict__ hist, int T) {
+  __shared__ int wtot[4];
+  const int d = threadIdx.x, lane = d & 63, wave = d >> 6;
+  int* h = hist + (size_t)blockIdx.x * T * 256;
+  int total = 0;
+  for (int t = 0; t < T; ++t) total += h[t * 256 + d];            // coalesced across the digits
+  int incl = total;                                               // exclusive scan over the 256 digit totals
 #pragma unroll
-      for (int s = 1; s < 64; s <<= 1) {
-        const int up = __shfl_up(incl, s);
-        if (lane >= s) incl += up;
+  for (int s = 1; s < 64; s <<= 1) {
+    const int up = __shfl_up(incl, s);
+    if (lane >= s) incl += up;
+  }
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  int run = incl - total;
+  for (int w = 0; w < wave; ++w) run += wtot[w];
+  for (int t = 0; t < T; ++t) {                                   // same digit, earlier tiles
+    const int c = h[t * 256 + d];
+    h[t * 256 + d] = run;
+    run += c;
+  }
+}
+
+// every key to  offs[tile][digit] + (keys of that digit earlier in the tile)
+__global__ __launch_bounds__(256) void vox_scatter(const unsigned long long* __restrict__ src_all, unsigned long long* __restrict__ dst_all,
+                                                     const int* __restrict__ offs, int N, int T, int q) {
+  __shared__ int base[256];
+  __shared__ int wcnt[4][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = blockIdx.x % T, b = blockIdx.x / T;
+  const unsigned long long* src = src_all + (size_t)b * N;
+  unsigned long long* dst = dst_all + (size_t)b * N;
+  base[tid] = offs[((size_t)b * T + tile) * 256 + tid];
+#pragma unroll 1
+  for (int r = 0; r < VT / 256; ++r) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) wcnt[w][tid] = 0;
+    __syncthreads();
+    const int i = tile * VT + r * 256 + tid;
+    const bool valid = i < N;
+    const unsigned long long key = valid ? src[i] : 0ull;
+    const unsigned d = ((unsigned)(key >> 20) >> (8 * q)) & 255u;
+    unsigned long long peers = __ballot(valid);                   // narrowed down to the lanes holding the same digit
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const bool set = (d >> bit) & 1u;
+      const unsigned long long bb = __ballot(set);
+      peers &= set ? bb : ~bb;
+    }
+    const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+    if (valid && rank == 0) wcnt[wave][d] = __popcll(peers);
+    __syncthreads();
+    {                                                             // thread = digit: this round's waves in order, then advance the base
+      int run = base[tid];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int c = wcnt[w][tid];
+        wcnt[w][tid] = run;
+        run += c;
       }
-      if (lane == 63) wtot[wave] = incl;
-      base[tid] = incl - c;                                     // within the wave for now
+      base[tid] = run;
     }
     __syncthreads();
-    if (tid < 256) {
-      int off = 0;
-      for (int w = 0; w < wave; ++w) off += wtot[w];
-      base[tid] += off;
-    }
-    __syncthreads();
-    for (int tile0 = 0; tile0 < N; tile0 += 1024) {
-      for (int e = tid; e < 16 * 256; e += 1024) (&wcnt[0][0])[e] = 0;
-      __syncthreads();
-      const int i = tile0 + tid;
-      const bool valid = i < N;
-      const unsigned long long key = valid ? src[i] : 0ull;
-      const unsigned d = ((unsigned)(key >> 20) >> (8 * q)) & 255u;
-      unsigned long long peers = __ballot(valid);
-#pragma unroll
-      for (int bit = 0; bit < 8; ++bit) {
-        const bool set = (d >> bit) & 1u;
-        const unsigned long long bb = __ballot(set);
-        peers &= set ? bb : ~bb;
-      }
-      const int rank = __popcll(peers & ((1ull << lane) - 1ull));
-      if (valid && rank == 0) wcnt[wave][d] = __popcll(peers);
-      __syncthreads();
-      if (tid < 256) {
-        int run = base[tid];
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-          const int c = wcnt[w][tid];
-          wcnt[w][tid] = run;
-          run += c;
-        }
-        base[tid] = run;
-      }
-      __syncthreads();
-      if (valid) dst[wcnt[wave][d] + rank] = key;
-      __syncthreads();
-    }
-    unsigned long long* t = src; src = dst; dst = t;
-    __threadfence_block();
+    if (valid) dst[wcnt[wave][d] + rank] = key;
     __syncthreads();
   }
 }
@@ -140,18 +153,43 @@ __global__ __launch_bounds__(256) void vox_heads(const unsigned long long* __res
   }
 }
 
-// one workgroup per frame: exclusive scan of (head_flag != 0) in point order -> voxel id; count -> num_voxels
-__global__ __launch_bounds__(1024) void vox_scan(const int* __restrict__ head_flag, int* __restrict__ vid,
-                                                  int* __restrict__ num_voxels, int N, int max_voxels) {
-  __shared__ int wsum[16];
-  __shared__ int carry;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) carry = 0;
+// tcount[frame][tile] = segment heads among the tile's 1024 points
+__global__ __launch_bounds__(256) void vox_flagcount(const int* __restrict__ head_flag, int* __restrict__ tcount, int N, int T) {
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = blockIdx.x % T, b = blockIdx.x / T;
+  int c = 0;
+#pragma unroll
+  for (int r = 0; r < VT / 256; ++r) {
+    const int n = tile * VT + r * 256 + tid;
+    c += (n < N && head_flag[(size_t)b * N + n] != 0) ? 1 : 0;
+  }
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) c += __shfl_xor(c, s);
+  if (lane == 0) wsum[wave] = c;
   __syncthreads();
-  for (int base = 0; base < N; base += 1024) {
-    const int n = base + tid;
+  if (tid == 0) tcount[(size_t)b * T + tile] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// voxel id of every point = heads before it in POINT order: the tiles before this one (summed here, at most 1024 counts) + an
+// in-tile scan in point order; the frame's last tile also leaves num_voxels
+__global__ __launch_bounds__(256) void vox_vid(const int* __restrict__ head_flag, const int* __restrict__ tcount, int* __restrict__ vid,
+                                                 int* __restrict__ num_voxels, int N, int T, int max_voxels) {
+  __shared__ int wsum[4];
+  __shared__ int carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = blockIdx.x % T, b = blockIdx.x / T;
+  int before = 0;
+  for (int t = tid; t < tile; t += 256) before += tcount[(size_t)b * T + t];
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) before += __shfl_xor(before, s);
+  if (lane == 0) wsum[wave] = before;
+  __syncthreads();
+  if (tid == 0) carry = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  __syncthreads();
+#pragma unroll 1
+  for (int r = 0; r < VT / 256; ++r) {
+    const int n = tile * VT + r * 256 + tid;
     const int f = (n < N && head_flag[(size_t)b * N + n] != 0) ? 1 : 0;
-    int incl = f;                                             // inclusive scan inside the wave
+    int incl = f;                                                 // inclusive scan inside the wave
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) {
       const int t = __shfl_up(incl, s);
@@ -164,10 +202,10 @@ __global__ __launch_bounds__(1024) void vox_scan(const int* __restrict__ head_fl
     const int excl = carry + woff + incl - f;
     if (n < N) vid[(size_t)b * N + n] = f ? excl : -1;
     __syncthreads();
-    if (tid == 1023) carry = excl + f;
+    if (tid == 255) carry = excl + f;
     __syncthreads();
   }
-  if (tid == 0) num_voxels[b] = carry < max_voxels ? carry : max_voxels;
+  if (tile == T - 1 && tid == 0) num_voxels[b] = carry < max_voxels ? carry : max_voxels;
 }
 
 // one wave per segment head: copy the first max_points points of the voxel, write coords / counts
@@ -241,8 +279,8 @@ __global__ __launch_bounds__(256) void scatter_write(const float* __restrict__ f
 }  // namespace
 
 extern "C" size_t bevf_voxelize_work_bytes(int B, int N) {
-  const long long n = (long long)B * N;
-  return (size_t)n * 16 + (size_t)n * 8 + 256;                           // keys (two buffers), head_flag + vid
+  const long long n = (long long)B * N, T = (N + VT - 1) / VT;
+  return (size_t)n * 16 + (size_t)n * 8 + (size_t)B * T * 257 * 4 + 256;   // keys (two buffers), head_flag + vid, tile histograms + counts
 }
 
 extern "C" int bevf_voxelize_f32(const bevf_voxelize_desc* d, void* stream) {
@@ -270,19 +308,30 @@ extern "C" int bevf_voxelize_f32(const bevf_voxelize_desc* d, void* stream) {
   int* vid = head_flag + n;
   const unsigned grid = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(vox_keys, dim3(grid), dim3(256), 0, st, a, keys_in);
-  // frame (12 bits) | cell (32 bits) | point (20 bits).  Frames are independent: each is sorted by one workgroup on as many
-  // 8-bit digits as the grid's cell count needs (the invalid cell, all ones, then still sorts behind every valid cell)
+  // frame (12 bits) | cell (32 bits) | point (20 bits).  Frames are independent slices; each is sorted on as many 8-bit digits as
+  // the grid's cell count needs (the invalid cell, all ones, then still sorts behind every valid cell)
   const unsigned long long ncells = (unsigned long long)a.gx * a.gy * a.gz;
   int passes = 1;
   while (passes < 4 && (1ull << (8 * passes)) <= ncells) ++passes;
-  hipLaunchKernelGGL(vox_sort, dim3(d->B), dim3(1024), 0, st, keys_in, keys, d->N, passes);
-  if ((passes & 1) == 0) keys = keys_in;                         // an even number of passes ends in the first buffer
+  const int T = (d->N + VT - 1) / VT;
+  int* hist = vid + n;
+  int* tcount = hist + (size_t)d->B * T * 256;
+  const dim3 tiles((unsigned)(d->B * T));
+  unsigned long long *src = keys_in, *dst = keys;
+  for (int q = 0; q < passes; ++q) {
+    hipLaunchKernelGGL(vox_hist, tiles, dim3(256), 0, st, src, hist, d->N, T, q);
+    hipLaunchKernelGGL(vox_offsets, dim3(d->B), dim3(256), 0, st, hist, T);
+    hipLaunchKernelGGL(vox_scatter, tiles, dim3(256), 0, st, src, dst, hist, d->N, T, q);
+    unsigned long long* t = src; src = dst; dst = t;
+  }
+  keys = src;                                                    // the buffer the last pass wrote
   if (hipMemsetAsync(head_flag, 0, (size_t)n * sizeof(int), st) != hipSuccess) {
     bevf_set_error("voxelize: memset failed");
     return BEVF_ERR_LAUNCH;
   }
   hipLaunchKernelGGL(vox_heads, dim3(grid), dim3(256), 0, st, keys, head_flag, n, d->N);
-  hipLaunchKernelGGL(vox_scan, dim3(d->B), dim3(1024), 0, st, head_flag, vid, d->num_voxels, d->N, d->max_voxels);
+  hipLaunchKernelGGL(vox_flagcount, tiles, dim3(256), 0, st, head_flag, tcount, d->N, T);
+  hipLaunchKernelGGL(vox_vid, tiles, dim3(256), 0, st, head_flag, tcount, vid, d->num_voxels, d->N, T, d->max_voxels);
   hipLaunchKernelGGL(vox_fill, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, st, a, keys, head_flag, vid,
                      d->voxel_features, (long long*)d->voxel_coords, d->num_points);
   return bevf_check_launch("bevf_voxelize_f32");

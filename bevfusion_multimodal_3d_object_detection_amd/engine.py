@@ -383,6 +383,9 @@ class PointNetEngine(_Engine):
         return y
 
 
+FUSE_VFE = True              # VFELayer with <= 16 input channels as one kernel (False: pointwise_smallk + group_max, bit-identical)
+
+
 class VFEEngine(_Engine):
     """VFELayer (ref src/encoders.py:431-455): Linear + BN1d + ReLU per point, max over the points of a voxel."""
 
@@ -402,9 +405,12 @@ class VFEEngine(_Engine):
         B, Nv, P, Cc = x.shape
         G, M = B * Nv, B * Nv * P
         if Cc <= 16:
+            out = torch.empty(G, self.cout, device=x.device)
+            if FUSE_VFE:
+                L.vfe_smallk_max(x, self.w, self.scale, self.shift, out, G, P, Cc, self.cout)
+                return out
             t = self.buf("pts", M * self.cout)
             L.pointwise_smallk(x, self.w, self.scale, self.shift, t, M, Cc, self.cout, True)
-            out = torch.empty(G, self.cout, device=x.device)
             L.group_max(t, out, G, P, self.cout)
             return out
         gmax = torch.zeros(G, self.cout, dtype=torch.int32, device=x.device)

@@ -132,6 +132,11 @@ int bevf_pointnet_front_pack_f32(const float* w, float* wf, int Cout, int Cin, v
 /* y[g][c] = max over the P rows of group g: the per-voxel max of VFELayer ("pillar reduction"),
  * ref src/encoders.py:451-452.  x: [G][P][C] post-ReLU point features -> y: [G][C].           */
 int bevf_group_max_f32(const float* x, float* y, int G, int P, int C, void* stream);
+/* The whole VFELayer for K <= 16 input channels in one pass (ref src/encoders.py:431-455): y[g][n] = max over the P rows of
+ * group g of relu((x[g][p][:] . w[n][:]) * scale[n] + shift[n]); bit-identical to bevf_pointwise_smallk_f32 followed by
+ * bevf_group_max_f32, without the [G][P][Cout] intermediate.  x: [G][P][K], w: [Cout][K], y: [G][Cout].               */
+int bevf_vfe_smallk_max_f32(const float* x, const float* w, const float* scale, const float* shift, float* y, int G, int P,
+                            int K, int Cout, void* stream);
 
 /* One radar sweep -> 256-d feature: 4 x (Conv1d k=1 + BN + ReLU) + max over points, all in
  * LDS, one workgroup per (radar, batch element, 32-point chunk); `out` must be ZERO-FILLED (the chunk maxima
