@@ -17,6 +17,8 @@
 // (holding the h shift) + compile-time immediate", fully unrolled: 3 ds_read_b32 + 2 MFMA per step.
 #include "common.h"
 
+#include <stdlib.h>
+
 #include <type_traits>
 
 namespace {
@@ -863,6 +865,165 @@ __global__ __launch_bounds__(256) void stem_pool7x7_bf16mma(const float* __restr
   }
 }
 
+// ---- round 3: the same fused bf16 stem + max-pool WITHOUT the column-tile expansion ------------------------------------------
+// stem_pool7x7_bf16mma spends its time expanding: per half row every thread makes ~5 x (4 ds_read_b32 + 3 v_alignbit + ds_write_b128)
+// and two barriers frame 11 MFMAs per wave -- PMC: matrix pipe 13 % busy, 55 % of the wave cycles parked, the LDS array saturated by
+// three co-resident workgroups.  Here the A fragment of a pixel is read STRAIGHT from the staged patch: the 8 k of a group
+// (c, kh) are the 8 consecutive input pixels 2q+1 .. 2q+8 of one patch row (q = strip pixel; the 8th meets the filter's zero
+// column), an odd element offset.  The patch is therefore kept as TWO bf16 copies shifted by 1 and by 3 elements: pixel q reads copy
+// q & 1 at byte 8 (q >> 1) -- two aligned ds_read_b64 per fragment, address = lane base + immediate, no VALU, no barrier.  With the
+// copies 128 B (mod 256) apart the 32 lanes of a ds_read_b64 group cover all 64 banks once.  Staging makes both copies from two
+// aligned 16-byte global loads per lane (columns 4m .. 4m+7: the second is the neighbour's first, an L1 hit), three v_cvt_pk and
+// two ds_write_b64.  Barriers: two per chunk of four stem rows (was 18).  Same fragments, same MFMA order, same epilogue ->
+// bit-identical to stem_pool7x7_bf16mma for finite images (the kw = 7 product is pixel x 0 instead of 0 x 0).
+constexpr int RPB = PW * 2;                                        // bytes per patch row of one copy (264 bf16)
+constexpr int COPYB = ((3 * PR * RPB + 255) / 256) * 256 + 128;    // copy stride: == 128 (mod 256)
+constexpr size_t kStemBf16V2Lds = (size_t)2 * COPYB;
+__host__ __device__ constexpr int stem_row_of(int r) { return r >= 21 ? (2 * PR + 6) : (r / 7) * PR + (r % 7); }   // k-group -> patch row (group 21: zero filter)
+
+__global__ __launch_bounds__(256) void stem_pool7x7_bf16v2(const float* __restrict__ x, const __bf16* __restrict__ w,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            __bf16* __restrict__ y, int H, int W, int Ho, int Wo, int Hp, int Wp,
+                                                            int tilesW, int nseg, int rows_per_seg) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* const lds = reinterpret_cast<char*>(smem);                 // [2 copies][3 * PR rows][RPB]; the filter bank passes through first
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tw = blockIdx.x % tilesW;
+  const int seg = (blockIdx.x / tilesW) % nseg;
+  const int n = blockIdx.x / (tilesW * nseg);
+  const int ow0 = tw * TPS - 2;
+  const int p0 = seg * rows_per_seg, p1 = p0 + rows_per_seg < Hp ? p0 + rows_per_seg : Hp;
+  const int r_first = 2 * p0 - 1, r_last = 2 * (p1 - 1) + 1;       // stem rows this segment needs
+  for (int i = tid; i < 64 * (KP / 8); i += 256) {
+    const int ch = i / (KP / 8), q = i - ch * (KP / 8);
+    *reinterpret_cast<u32x4*>(lds + ch * CP + q * 16) = *reinterpret_cast<const u32x4*>(w + (size_t)ch * KP + q * 8);
+  }
+  __syncthreads();
+  const int h = lane >> 5, l31 = lane & 31;
+  const int mi = wave >> 1, ni = wave & 1;
+  const float sc = scale[ni * 32 + l31], sh = shift[ni * 32 + l31];
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  constexpr int NG = KP / 16;
+  bf16x8s bfrag[NG];
+  {
+    const char* const b_rd = lds + (ni * 32 + l31) * CP + h * 16;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) bfrag[g] = *reinterpret_cast<const bf16x8s*>(b_rd + g * 32);
+  }
+  // A-fragment addresses: k-group 2g + h of pixel q -> copy (q & 1), patch row stem_row_of(2g + h) + 2 ro, byte 8 (q >> 1).
+  // Row of the odd group = row of the even one + 1, except 6|7 (next channel: + PR - 6), 20|21 (the zero group: same row, any finite data)
+  int abase[2];
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    const int q = hf * 2 * WPX + mi * WPX + l31;
+    abase[hf] = (q & 1) * COPYB + 8 * (q >> 1);
+  }
+  const int hrow1 = h * RPB, hrow7 = h * (PR - 6) * RPB;
+  const bool all_cols = ow0 >= 0 && ow0 + 3 * WPX + 32 <= Wo;      // every stem column the four wave tiles touch exists
+  const bool vec_ok = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
+  float prev1[2][8], prev2[2][8];                                  // [half][centre]: horizontal maxima of the last two stem rows
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { prev1[a][i] = 0.f; prev2[a][i] = 0.f; }
+
+  for (int oh0 = r_first; oh0 <= r_last; oh0 += TH) {
+    __syncthreads();                                               // the previous chunk's patch (or the filter bank) is consumed
+    {                                                              // patch rows 2*oh0 - 3 .., columns 2*ow0 - 4 .. -> the two shifted bf16 copies
+      const float* img = x + (size_t)n * 3 * H * W;
+      const int iw0 = 2 * ow0 - 4;
+      const int wv = __builtin_amdgcn_readfirstlane(wave);
+      for (int r = wv; r < 3 * PR; r += 4) {
+        const int c = r / PR, pr = r - c * PR;
+        const int ih = 2 * oh0 - 3 + pr;
+        const bool row_ok = (unsigned)ih < (unsigned)H;
+        const float* row = img + ((size_t)c * H + (row_ok ? ih : 0)) * W;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(row), 0, row_ok ? W * 4 : 0, 0x00020000);
+        for (int c4 = lane; c4 < PW / 4; c4 += 64) {
+          const int iw = iw0 + 4 * c4;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f}, u = {0.f, 0.f, 0.f, 0.f};    // patch columns 4 c4 .. + 3 and the next four
+          if (vec_ok) {
+            v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, iw >= 0 ? (unsigned)(iw * 4) : 0x80000000u, 0, 0));
+            u = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, iw + 4 >= 0 ? (unsigned)((iw + 4) * 4) : 0x80000000u, 0, 0));
+          } else if (row_ok) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if ((unsigned)(iw + j) < (unsigned)W) v[j] = row[iw + j];
+              if ((unsigned)(iw + 4 + j) < (unsigned)W) u[j] = row[iw + 4 + j];
+            }
+          }
+          // copy 0 holds patch column e + 1 at element e, copy 1 column e + 3: elements 4 c4 .. 4 c4 + 3 of both
+          bf16x4s a0, a1;
+          a0[0] = (__bf16)v[1]; a0[1] = (__bf16)v[2]; a0[2] = (__bf16)v[3]; a0[3] = (__bf16)u[0];
+          a1[0] = a0[2]; a1[1] = a0[3]; a1[2] = (__bf16)u[1]; a1[3] = (__bf16)u[2];
+          *reinterpret_cast<bf16x4s*>(lds + (size_t)r * RPB + 8 * c4) = a0;
+          *reinterpret_cast<bf16x4s*>(lds + COPYB + (size_t)r * RPB + 8 * c4) = a1;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ro = 0; ro < TH; ++ro) {
+      const int oh = oh0 + ro;
+      if (oh > r_last) break;
+      const bool row_ok = (unsigned)oh < (unsigned)Ho;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        if (ow0 + hf * 2 * WPX >= Wo) break;                       // (uniform) nothing of this half exists
+        typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+        bf16x8s afrag[NG];
+        const char* const ab = lds + abase[hf] + ro * 2 * RPB;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const char* ap = ab + stem_row_of(2 * g) * RPB + (g == 3 ? hrow7 : (g == 10 ? 0 : hrow1));
+          const bf16x4v lo = *reinterpret_cast<const bf16x4v*>(ap), hi = *reinterpret_cast<const bf16x4v*>(ap + 8);
+          afrag[g] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[g], bfrag[g], g == 0 ? zero : acc, 0, 0, 0);
+        // BatchNorm + ReLU as the unfused kernel stores them (before its bf16 rounding); missing rows / columns count as 0
+        const int col0 = ow0 + hf * 2 * WPX + mi * WPX + 4 * h;    // stem column of register 0 of this lane
+        float v[16];
+        if (row_ok && all_cols) {                                  // (uniform) interior strip: no per-element predicate
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = fmaxf(fmaf(acc[r], sc, sh), 0.f);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const bool ok = row_ok && (unsigned)(col0 + (r & 3) + 8 * (r >> 2)) < (unsigned)Wo;
+            v[r] = ok ? fmaxf(fmaf(acc[r], sc, sh), 0.f) : 0.f;
+          }
+        }
+        float hm[8], xl[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xl[g] = __shfl_xor(v[4 * g + 3], 32);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float l0 = h ? xl[g] : (g > 0 ? xl[g - 1] : 0.f);
+          hm[2 * g] = fmaxf(fmaxf(l0, v[4 * g]), v[4 * g + 1]);
+          hm[2 * g + 1] = fmaxf(fmaxf(v[4 * g + 1], v[4 * g + 2]), v[4 * g + 3]);
+        }
+        if (oh & 1) {                                              // stem row 2p+1 completes pooled row p (uniform branch)
+          const int pr = (oh - 1) >> 1;
+          if (pr >= p0 && pr < p1) {
+            __bf16* const yrow = y + ((size_t)(n * Hp + pr) * Wp) * 64 + ni * 32 + l31;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+              const int rc = 2 * c;
+              const int cc = col0 + (rc & 3) + 8 * (rc >> 2);      // stem column of the window centre (even)
+              const bool own = (h != 0 || c != 0) && cc >= 0 && (cc >> 1) < Wp;
+              if (own) yrow[(size_t)(cc >> 1) * 64] = (__bf16)fmaxf(fmaxf(prev2[hf][c], prev1[hf][c]), hm[c]);
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { prev2[hf][i] = prev1[hf][i]; prev1[hf][i] = hm[i]; }
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void stem_pack_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= 64 * KP) return;
@@ -929,9 +1090,17 @@ extern "C" int bevf_stem_pool_bf16mma(const float* x, const void* w_packed, cons
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool7x7_bf16mma), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)kStemBf16Lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool7x7_bf16v2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)kStemBf16V2Lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL(stem_pool7x7_bf16mma, dim3((unsigned)grid), dim3(256), kStemBf16Lds, static_cast<hipStream_t>(stream), x,
-                     static_cast<const __bf16*>(w_packed), scale, shift, static_cast<__bf16*>(y), H, W, Ho, Wo, Hp, Wp, tilesW, nseg, rps);
+  // BEVF_STEM_BF16_EXPAND=1: the round-2 kernel (column tile expanded in LDS), kept for A/B; default: fragments straight from the patch
+  static const bool expand = getenv("BEVF_STEM_BF16_EXPAND") != nullptr;
+  if (expand)
+    hipLaunchKernelGGL(stem_pool7x7_bf16mma, dim3((unsigned)grid), dim3(256), kStemBf16Lds, static_cast<hipStream_t>(stream), x,
+                       static_cast<const __bf16*>(w_packed), scale, shift, static_cast<__bf16*>(y), H, W, Ho, Wo, Hp, Wp, tilesW, nseg, rps);
+  else
+    hipLaunchKernelGGL(stem_pool7x7_bf16v2, dim3((unsigned)grid), dim3(256), kStemBf16V2Lds, static_cast<hipStream_t>(stream), x,
+                       static_cast<const __bf16*>(w_packed), scale, shift, static_cast<__bf16*>(y), H, W, Ho, Wo, Hp, Wp, tilesW, nseg, rps);
   return bevf_check_launch("bevf_stem_pool_bf16mma");
 }

@@ -321,7 +321,7 @@ def test_eval_after_train_uses_new_weights(gpu):
 def test_train_step_with_radar_against_oracle_autograd(gpu):
     """camera+lidar+radar (shared radar encoder used five times per step, BN stats updated five times):
     gradients of every parameter against torch autograd on the CPU oracle."""
-    from oracle import ref_model, ref_targets
+    from oracle import ref_model
     ora = ref_model.make_detector("camera+lidar+radar", 50, 50)
     synth.fill_state_dict_(ora, 77)
     ora.train()
@@ -330,51 +330,37 @@ def test_train_step_with_radar_against_oracle_autograd(gpu):
     model = model.cuda().train()
     imgs, pts, radars = synth.frame_inputs(2, 2, 64, 96, 200, 4, 5, 20, 7, seed=123)
     boxes, labels = cases.target_inputs(cases.TRAIN_CASE)
-    tgt_ref = ref_targets.make_targets(boxes, labels)
-    pred_ref = ora(imgs, pts, radars)
-    loss_ref = ref_targets.centernet_loss(pred_ref, tgt_ref)["total_loss"]
-    loss_ref.backward()
-    pred = model(imgs.cuda(), pts.cuda(), [r.cuda() for r in radars])
-    tgt = ct.prepare_centernet_targets({"gt_boxes": boxes, "gt_labels": labels}, gpu)
-    loss = ct.CenterNetLoss()(pred, tgt)["total_loss"]
-    assert abs(float(loss.detach()) - float(loss_ref)) <= 1e-4 * abs(float(loss_ref))
-    loss.backward()
-    gref = dict(ora.named_parameters())
-    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in ora.parameters())))
-    bad, loose = [], 0
-    for name, p in model.named_parameters():
-        r = gref[name].grad
-        assert p.grad is not None, name
-        err = float((p.grad.cpu() - r).abs().max())
-        # whole-network gradients are discontinuous in the forward values (ReLU masks, max-pool / point-max argmax):
-        # 1e-6 forward differences flip a few decisions, so tensors agree to ~1e-2 of their scale, not to 1e-5
-        # (the per-op backward tests above hold 2e-5)
-        if err > 2e-2 * float(r.abs().max()) + 2e-6 * gn:
-            bad.append((name, err, float(r.abs().max())))
-        if err > 3e-3 * float(r.abs().max()) + 2e-6 * gn:
-            loose += 1
-    assert not bad, bad[:5]
-    assert loose <= 12, loose                                      # and nearly all of the ~250 tensors agree to 3e-3
-    for (n1, b1), (n2, b2) in zip(model.named_buffers(), ora.named_buffers()):           # BN running statistics
-        assert n1 == n2 and rel_err(b1.cpu().float(), b2.float()) <= 2e-5, n1
+    assert _grad_check_against_oracle(model, ora, imgs, pts, radars, boxes, labels, gpu) >= 140
 
 
-def _grad_check_against_oracle(model, ora, imgs, pts, radars, boxes, labels, gpu):
-    """One forward/backward on both; returns after asserting every trainable parameter's gradient (tolerances as in
-    test_train_step_with_radar_against_oracle_autograd: ReLU masks / argmaxes are discontinuous in the forward values)."""
+def _grad_check_against_oracle(model, ora, imgs, pts, radars, boxes, labels, gpu, tol=1e-4, loose_tol=None):
+    """One forward/backward on the device model and on the oracle IN FLOAT64; every trainable parameter's gradient must agree to
+    1e-4 of the tensor's scale (+ an absolute floor of 2e-6 of the whole gradient's norm for the tensors whose true gradient is zero:
+    the conv / linear biases in front of a BatchNorm); BN running statistics to 2e-5.
+    Round 3: the earlier form compared against the FP32 oracle and allowed 2e-2 / an eighth of the tensors past
+    3e-3, blamed on ReLU / argmax flips.  A probe against fp64 autograd showed that most of that slack was the fp32 ORACLE's rounding:
+    on the camera+lidar+radar case all 144 device gradients are within 1e-4 of the fp64 truth.  Real flips do exist -- a ReLU input
+    within ~1e-6 of zero, taken the other way by a forward pass that is 3e-6-accurate, moves every upstream tensor by 0.3-2 % (seen on
+    lidar+radar at batch 2; 11 of 12 seeds scanned had at least one) -- so the whole-network check is TIGHT (tol 1e-4, no tensor may
+    miss) on the one case pinned flip-free (camera+lidar+radar, seed 123: the forward kernels are deterministic, so that is reproducible),
+    and the secondary cases (other radar fusions, frozen BatchNorm), whose job is to show that the right tensors receive gradients at
+    all, pass `tol=2e-2, loose_tol=3e-3` (at most an eighth of the tensors past loose_tol).  Holding those to 1e-4 as well needs the
+    device's ReLU decisions replayed into the oracle (not built).  The per-op backward tests hold every kernel to 2e-5 on its own."""
     from oracle import ref_targets
-    tgt_ref = ref_targets.make_targets(boxes, labels)
-    loss_ref = ref_targets.centernet_loss(ora(imgs, pts, radars), tgt_ref)["total_loss"]
+    ora = ora.double()
+    d = lambda t: None if t is None else t.double()
+    tgt_ref = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in ref_targets.make_targets(boxes, labels).items()}
+    loss_ref = ref_targets.centernet_loss(ora(d(imgs), d(pts), [r.double() for r in radars] if radars else None), tgt_ref)["total_loss"]
     loss_ref.backward()
     cu = lambda t: None if t is None else t.cuda()
     pred = model(cu(imgs), cu(pts), [r.cuda() for r in radars] if radars else None)
     tgt = ct.prepare_centernet_targets({"gt_boxes": boxes, "gt_labels": labels}, gpu)
     loss = ct.CenterNetLoss()(pred, tgt)["total_loss"]
-    assert abs(float(loss.detach()) - float(loss_ref)) <= 1e-4 * abs(float(loss_ref))
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-5 * abs(float(loss_ref.detach()))
     loss.backward()
     gref = dict(ora.named_parameters())
-    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in ora.parameters() if p.grad is not None)))
-    bad, loose, checked = [], 0, 0
+    gn = float(torch.sqrt(sum((p.grad ** 2).sum() for p in ora.parameters() if p.grad is not None)))
+    bad, checked, loose = [], 0, 0
     for name, p in model.named_parameters():
         r = gref[name].grad
         if not gref[name].requires_grad:
@@ -382,15 +368,15 @@ def _grad_check_against_oracle(model, ora, imgs, pts, radars, boxes, labels, gpu
             continue
         assert p.grad is not None, name
         checked += 1
-        err = float((p.grad.cpu() - r).abs().max())
-        if err > 2e-2 * float(r.abs().max()) + 2e-6 * gn:
+        err = float((p.grad.cpu().double() - r).abs().max())
+        if err > tol * float(r.abs().max()) + 2e-6 * gn:
             bad.append((name, err, float(r.abs().max())))
-        if err > 3e-3 * float(r.abs().max()) + 2e-6 * gn:
+        if loose_tol is not None and err > loose_tol * float(r.abs().max()) + 2e-6 * gn:
             loose += 1
     assert not bad, bad[:5]
-    assert loose <= max(6, checked // 8), (loose, checked)   # ReLU-mask / argmax flips (forward values differ by ~1e-7) move a few tensors past 3e-3
+    assert loose <= max(6, checked // 8), (loose, checked)
     for (n1, b1), (n2, b2) in zip(model.named_buffers(), ora.named_buffers()):           # BN running statistics
-        assert n1 == n2 and rel_err(b1.cpu().float(), b2.float()) <= 2e-5, n1
+        assert n1 == n2 and rel_err(b1.cpu().double(), b2.double()) <= 2e-5, n1
     return checked
 
 
@@ -409,7 +395,7 @@ def test_train_step_radar_max_mean_fusion(gpu, method):
     model = model.cuda().train()
     _, pts, radars = synth.frame_inputs(2, 0, 0, 0, 200, 4, 5, 20, 7, seed=124)
     boxes, labels = cases.target_inputs(cases.TRAIN_CASE)
-    n = _grad_check_against_oracle(model, ora, None, pts, radars, boxes, labels, gpu)
+    n = _grad_check_against_oracle(model, ora, None, pts, radars, boxes, labels, gpu, tol=2e-2, loose_tol=3e-3)
     assert n > 40 and not any("fusion_fc" in k for k, _ in model.named_parameters())
 
 
@@ -439,7 +425,7 @@ def test_freeze_bn_under_model_train(gpu):
     imgs, pts, _ = synth.frame_inputs(2, 2, 64, 96, 200, 4, seed=125)
     boxes, labels = cases.target_inputs(cases.TRAIN_CASE)
     before = model.camera_encoder.layer2[0].bn1.running_mean.clone()
-    _grad_check_against_oracle(model, ora, imgs, pts, None, boxes, labels, gpu)
+    _grad_check_against_oracle(model, ora, imgs, pts, None, boxes, labels, gpu, tol=2e-2, loose_tol=3e-3)
     assert model.camera_encoder.bn1.weight.grad is None and model.camera_encoder.layer3[1].bn2.bias.grad is None
     assert model.fusion.bev_fusion[1].weight.grad is not None                 # BatchNorms outside the camera encoder learn
     assert not torch.equal(before, model.camera_encoder.layer2[0].bn1.running_mean)
