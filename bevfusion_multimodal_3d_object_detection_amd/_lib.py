@@ -133,6 +133,7 @@ SIGNATURES = {
     "bevf_conv3x3_bf16_ct": (C.c_int, [C.c_int]),
     "bevf_conv3x3_pack_bf16": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 2 + [C.c_void_p]),
     "bevf_conv3x3_bf16": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "bevf_debug_conv3x3_stamps": (C.c_int, [C.c_void_p]),
     "bevf_stem_pack_bf16": (C.c_int, [C.c_void_p] * 3),
     "bevf_stem_conv7x7_bf16mma": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_stem_pool_bf16mma": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p]),
@@ -329,7 +330,8 @@ def conv3x3_bf16(x: torch.Tensor, wp: torch.Tensor, scale, shift, y: torch.Tenso
                  x_cs: int, Cout: int, y_cs: int, relu: bool, res: Optional[torch.Tensor] = None, res_cs: int = 0,
                  tile: int = 0) -> None:
     """3x3 / stride 1 / pad 1 convolution of bf16 activations (fp32 accumulate, folded BN, residual, ReLU); `wp` from
-    conv3x3_pack_bf16.  tile (64-channel tiles only): 0 auto, 1 = two patch buffers / two workgroups per CU, 2 = one / four."""
+    conv3x3_pack_bf16.  tile (64-channel tiles only): 0 auto, 1 = two patch buffers / two workgroups per CU, 2 = one / four,
+    3 = one buffer and 32-row blocks."""
     M = N * H * W
     dt = torch.bfloat16
     if x.numel() < (M - 1) * x_cs + Cin:

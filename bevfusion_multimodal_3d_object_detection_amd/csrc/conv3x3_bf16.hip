@@ -26,6 +26,8 @@
 
 namespace {
 
+constexpr int C3_AUTO_SHORTK = 1;                         // what `tile = 0` means for 64-channel tiles with Cin < 128 (1 | 2 | 3)
+
 struct C3Args {
   const void* x;        // bf16 NHWC, channel stride x_cs
   const void* wp;       // packed filters: [ct][chunk][tap][CT/16][64 lanes][8 bf16]
@@ -36,29 +38,43 @@ struct C3Args {
   int N, H, W, Cin, x_cs, Cout, y_cs, res_cs, relu;
   int TBY, TBX, nct;
   unsigned wbytes;      // size of the packed filter image
+  unsigned long long* stamps;   // diagnostic builds of a run (bevf_debug_conv3x3_stamps): 4 x s_memtime per workgroup, else null
 };
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int C3_PW = 18;                                 // patch width / height in pixels
+constexpr int C3_PW = 18;                                 // patch width in pixels (block width 16 + halo)
 constexpr int C3_PITCH = 20;                              // patch row pitch in the LDS image, pixels (see the read addresses in the kernel)
-constexpr int C3_PATCH_BYTES = 24 * 1024;                 // 24 LDS-DMA pieces of 64 slots >= 18 x 20 x 4 slots
 
 // CT = output channels per workgroup (64: waves 4 x 1, 128: waves 2 x 2; a wave always owns 64 channels).
 // PB = patch buffers: 2 = the next 32-channel chunk is prefetched under the current one (two workgroups per CU);
-//      1 = one buffer, 34 KB, FOUR workgroups per CU: occupancy instead of prefetch.
-template <int CT, int PB> struct C3Geo {
-  static constexpr int WN = CT / 64, WM = 4 / WN, MT = 16 / WM, NT = 4;
+//      1 = one buffer, FOUR workgroups per CU at BH = 16: occupancy instead of prefetch.
+// BH = block height in pixel rows: 16 (16 x 16 = 256 pixels) or, for 64-channel tiles, 32 (512 pixels: a wave owns 8 rows instead of 4;
+//      twice the MFMA work per tile, per barrier and per filter byte against the same fixed latencies -- for the short-K layers).
+template <int CT, int PB, int BH> struct C3Geo {
+  static constexpr int WN = CT / 64, WM = 4 / WN, MT = BH / WM, NT = 4;
+  static constexpr int PH = BH + 2;                       // patch height
+  static constexpr int PPW = (PH * C3_PITCH * 4 + 255) / 256;   // LDS-DMA pieces (64 slots of 16 B) per wave and patch chunk
+  static constexpr int PATCH_BYTES = 4 * PPW * 1024;
   static constexpr int WSTEP = CT * 64;                   // bytes of filters per (chunk, tap) step
-  static constexpr int RB = (CT == 64 && PB == 2) ? 4 : 3;   // ring slots; a step's filters are requested RB-1 steps ahead
-  static constexpr int LDS_BYTES = PB * C3_PATCH_BYTES + RB * WSTEP;
-  static constexpr int WG_PER_CU = PB == 1 ? 4 : 2;
-  static constexpr bool RES_EARLY = CT == 64 && PB == 2;  // residual requested in the prologue (32 registers; see the kernel)
+#ifndef C3_RB64
+#define C3_RB64 8
+#endif
+#ifndef C3_RB128
+#define C3_RB128 4
+#endif
+  // ring slots; a step's filters are requested RB-1 steps ahead.  The depth is not for the filters (L2 hits): loads retire in order, so
+  // a patch piece (HBM, 4-8k cycles under load) must land within RB-1 steps of its issue or the filter wait behind it stalls
+  static constexpr int RB = (CT == 64 && PB == 2) ? C3_RB64 : (CT == 128 ? C3_RB128 : 3);
+  static constexpr int LDS_BYTES = PB * PATCH_BYTES + RB * WSTEP;
+  static constexpr int WG_PER_CU = (PB == 1 && BH == 16) ? 4 : 2;
+  static constexpr bool RES_EARLY = CT == 64 && PB == 2 && BH == 16;  // residual requested in the prologue (32 registers; see the kernel)
 };
 
-template <int CT, int PB>
-__global__ __launch_bounds__(256, (C3Geo<CT, PB>::WG_PER_CU)) void conv3x3_bf16(const C3Args p) {
-  using Geo = C3Geo<CT, PB>;
+template <int CT, int PB, int BH>
+__global__ __launch_bounds__(256, (C3Geo<CT, PB, BH>::WG_PER_CU)) void conv3x3_bf16(const C3Args p) {
+  using Geo = C3Geo<CT, PB, BH>;
+  constexpr int C3_PATCH_BYTES = Geo::PATCH_BYTES;
   constexpr int WN = Geo::WN, MT = Geo::MT, NT = Geo::NT, WSTEP = Geo::WSTEP, RB = Geo::RB, D = RB - 1;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* const patch = lds;                                // [PB][C3_PATCH_BYTES]
@@ -72,7 +88,7 @@ __global__ __launch_bounds__(256, (C3Geo<CT, PB>::WG_PER_CU)) void conv3x3_bf16(
   // issuing an LDS-DMA costs its wave 60-180 cycles, and two waves carrying all of one kind become the step's critical path.)
   constexpr int NSH = 4;                                              // waves sharing the DMA duty
   const int role = wave;
-  constexpr int PPW = 24 / NSH, FPW = (CT / 16) / NSH;                // patch pieces per wave and chunk, filter pieces per wave and step
+  constexpr int PPW = Geo::PPW, FPW = (CT / 16) / NSH;                // patch pieces per wave and chunk, filter pieces per wave and step
 
   // ---- tile: ct-major numbering, so the workgroups running together share one filter slab in L2; XCD-contiguous ----
   const int nsp = p.N * p.TBY * p.TBX;
@@ -90,14 +106,14 @@ __global__ __launch_bounds__(256, (C3Geo<CT, PB>::WG_PER_CU)) void conv3x3_bf16(
   auto patch_dma = [&](unsigned soff, int buf, int j0, int j1, bool live) {   // this wave's pieces j0 .. j1-1 of a chunk
     int l = lane;
     asm volatile("" : "+v"(l));                                      // (opaque: keeps hipcc from hoisting the offsets out of the chunk loop)
-    const int iy0 = 16 * by - 1, ix0 = 16 * bx - 1;
+    const int iy0 = BH * by - 1, ix0 = 16 * bx - 1;
 #pragma unroll
     for (int j = j0; j < j1; ++j) {
       const int i = (NSH * j + role) * 64 + l;
       const int pix = i >> 2, kg = (i & 3) ^ (((pix >> 2) & 1) << 1);
-      const int py = (pix * 3277) >> 16, px = pix - py * C3_PITCH;         // pix / 20 for pix < 1024
+      const int py = (pix * 3277) >> 16, px = pix - py * C3_PITCH;         // pix / 20 for pix < 16384 / 4
       const int iy = iy0 + py, ix = ix0 + px;
-      const bool ok = live && px < C3_PW && py < C3_PW && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const bool ok = live && px < C3_PW && py < Geo::PH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
       const unsigned voff = ok ? (unsigned)((((n * p.H + iy) * p.W + ix) * p.x_cs + kg * 8) * 2) : kOob;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
           rsx, (__attribute__((address_space(3))) void*)(patch + buf * C3_PATCH_BYTES + (NSH * j + role) * 1024), 16, voff, soff, 0, 0);
@@ -137,7 +153,7 @@ __global__ __launch_bounds__(256, (C3Geo<CT, PB>::WG_PER_CU)) void conv3x3_bf16(
   const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)kOob, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, (int)kOob, 0x00020000);
   const int co0 = ct * CT + wn * 64 + 4 * kgl;
-  const int ox = 16 * bx + col, oy0 = 16 * by + wm * MT;
+  const int ox = 16 * bx + col, oy0 = BH * by + wm * MT;
   const unsigned pixel0 = (unsigned)((n * p.H + oy0) * p.W + ox);
   auto out_ok = [&](int mt) { return ox < p.W && oy0 + mt < p.H; };
   u32x2 rv[Geo::RES_EARLY ? MT : 1][NT];
@@ -147,7 +163,7 @@ __global__ __launch_bounds__(256, (C3Geo<CT, PB>::WG_PER_CU)) void conv3x3_bf16(
     for (int nt = 0; nt < NT; ++nt) dst[nt] = __builtin_amdgcn_raw_buffer_load_b64(rsr, ro, (unsigned)(nt * 32), 0);
   };
 
-  int mt_live = p.H - (16 * by + wm * MT);                            // pixel rows of this wave inside the image (wave-uniform)
+  int mt_live = p.H - (BH * by + wm * MT);                            // pixel rows of this wave inside the image (wave-uniform)
   mt_live = mt_live < 0 ? 0 : (mt_live > MT ? MT : mt_live);
   f32x4 acc[NT][MT];
 #pragma unroll
@@ -155,6 +171,11 @@ __global__ __launch_bounds__(256, (C3Geo<CT, PB>::WG_PER_CU)) void conv3x3_bf16(
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // (diagnostic only: p.stamps is null in every product launch; the stamps go to a buffer nothing else reads)
+  auto stamp = [&](int i) {
+    if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 4 + i] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
   // ---- prologue: filters of steps 0 .. D-1, patch chunk 0 (and the residual: one HBM round trip covers both) ----------------
 #pragma unroll
   for (int s = 0; s < D; ++s) ring_dma(s, s);
@@ -166,6 +187,7 @@ __global__ __launch_bounds__(256, (C3Geo<CT, PB>::WG_PER_CU)) void conv3x3_bf16(
     }
   }
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  stamp(1);
 
   // One step = one filter tap of one 32-channel chunk: MT x NT MFMAs per wave.  Issue order inside a step: the filter pieces of step
   // s + D, then (two-buffer variant, taps 0..5) one sixth of the NEXT chunk's patch; loads retire in order, so the wait at the step's
@@ -179,7 +201,8 @@ __global__ __launch_bounds__(256, (C3Geo<CT, PB>::WG_PER_CU)) void conv3x3_bf16(
       ns = ns >= RB ? ns - RB : ns;
       ring_dma(s + D, ns);
     }
-    if constexpr (PB == 2 && t < PPW) patch_dma(psoff, pbuf ^ 1, t, t + 1, pnext);   // one piece per step, taps 0 .. 5 (zeros past the last chunk)
+    static_assert(PB == 1 || PPW <= 9, "one patch piece per tap");
+    if constexpr (PB == 2 && t < PPW) patch_dma(psoff, pbuf ^ 1, t, t + 1, pnext);   // one piece per step, taps 0 .. PPW-1 (zeros past the last chunk)
     constexpr int LIVE = decltype(livec)::value;                    // pixel rows of this wave that take part (the rest lie below the image)
     if constexpr (LIVE > 0) {
       bf16x8 wf[NT], xf[LIVE];
@@ -238,6 +261,7 @@ __global__ __launch_bounds__(256, (C3Geo<CT, PB>::WG_PER_CU)) void conv3x3_bf16(
     default: kloop(std::integral_constant<int, MT>{}); break;
   }
 
+  stamp(2);
   // ---- epilogue: folded BN, residual, ReLU, bf16x4 stores --------------------------------------------------------------------
   f32x4 sc[NT], sh[NT];
 #pragma unroll
@@ -245,12 +269,25 @@ __global__ __launch_bounds__(256, (C3Geo<CT, PB>::WG_PER_CU)) void conv3x3_bf16(
     sc[nt] = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + co0 + nt * 16) : f32x4{1.f, 1.f, 1.f, 1.f};
     sh[nt] = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + co0 + nt * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  // Residual rows not requested in the prologue: a ring of RD rows in flight.  (In-kernel stamps, layer3: loading a row's residual
+  // right where it is needed made the epilogue EIGHT serial HBM round trips -- hipcc cannot hoist a load above the previous row's
+  // stores, y may alias res -- 21.5k of a workgroup's 103k cycles.)
+  constexpr int RD = (Geo::RES_EARLY || Geo::WG_PER_CU == 4) ? 1 : 4;     // (the 128-register variant keeps one row: no room for a ring)
+  u32x2 rq[RD][NT];
+  if constexpr (!Geo::RES_EARLY) {
+    if (p.res) {
+#pragma unroll
+      for (int mt = 0; mt < RD; ++mt) load_res(mt, rq[mt]);
+    }
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const unsigned yo = out_ok(mt) ? ((pixel0 + (unsigned)(mt * p.W)) * (unsigned)p.y_cs + (unsigned)co0) * 2u : kOob;
-    u32x2 (&rr)[NT] = rv[Geo::RES_EARLY ? mt : 0];
+    u32x2 rr[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) rr[nt] = Geo::RES_EARLY ? rv[Geo::RES_EARLY ? mt : 0][nt] : rq[mt % RD][nt];
     if constexpr (!Geo::RES_EARLY) {
-      if (p.res) load_res(mt, rr);
+      if (p.res && mt + RD < MT) load_res(mt + RD, rq[mt % RD]);   // the slot just read: the row RD ahead
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -271,6 +308,10 @@ __global__ __launch_bounds__(256, (C3Geo<CT, PB>::WG_PER_CU)) void conv3x3_bf16(
       for (int j = 0; j < 4; ++j) ob[j] = (__bf16)o[j];
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), rsy, yo, (unsigned)(nt * 32), 0);
     }
+  }
+  if (p.stamps) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (diagnostic: the stores have been acknowledged)
+    stamp(3);
   }
 }
 
@@ -315,6 +356,13 @@ extern "C" int bevf_conv3x3_pack_bf16(const void* w_ohwi, void* packed, int Cout
   return bevf_check_launch("bevf_conv3x3_pack_bf16");
 }
 
+static unsigned long long* g_c3_stamps = nullptr;
+// Diagnostic (tools/conv3x3_bench.py stamps): buf = device buffer of 4 x 8 bytes per workgroup of the NEXT launches, or null to stop
+extern "C" int bevf_debug_conv3x3_stamps(void* buf) {
+  g_c3_stamps = static_cast<unsigned long long*>(buf);
+  return BEVF_OK;
+}
+
 extern "C" int bevf_conv3x3_bf16(const bevf_conv_desc* d, void* stream) {
   BEVF_REQUIRE(d && d->x && d->w && d->y, "conv3x3_bf16: null x / w / y");
   BEVF_REQUIRE(d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1, "conv3x3_bf16: 3x3, stride 1, pad 1 only (got %dx%d s%d p%d)",
@@ -341,24 +389,28 @@ extern "C" int bevf_conv3x3_bf16(const bevf_conv_desc* d, void* stream) {
   a.relu = d->relu;
   a.TBY = (d->H + 15) / 16; a.TBX = (d->W + 15) / 16;
   a.wbytes = (unsigned)wbytes;
+  a.stamps = g_c3_stamps;
   const int CT = bevf_conv3x3_bf16_ct(d->Cout);
   a.nct = d->Cout / CT;
-  const long long ntiles = (long long)d->N * a.TBY * a.TBX * a.nct;
-  BEVF_REQUIRE(ntiles < (1ll << 31), "conv3x3_bf16: too many tiles");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  // tile: 0 = auto, 1 = two patch buffers (2 workgroups per CU), 2 = one (4 per CU; 64-channel tiles only).  Auto takes the single
-  // buffer for 64-channel tiles with Cin >= 128 (tools/conv3x3_bench.py: head 168 -> 155 us; layer1, two chunks only, is a tie)
-  constexpr int lds128 = C3Geo<128, 2>::LDS_BYTES, lds64 = C3Geo<64, 2>::LDS_BYTES, lds64s = C3Geo<64, 1>::LDS_BYTES;
+  // tile (64-channel tiles only): 0 = auto, 1 = two patch buffers (2 workgroups per CU), 2 = one (4 per CU), 3 = one buffer and 32-row
+  // blocks (2 per CU).  Auto: tools/conv3x3_bench.py
+  constexpr int lds128 = C3Geo<128, 2, 16>::LDS_BYTES, lds64 = C3Geo<64, 2, 16>::LDS_BYTES, lds64s = C3Geo<64, 1, 16>::LDS_BYTES,
+                lds64t = C3Geo<64, 1, 32>::LDS_BYTES;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16<64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds64);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16<128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds128);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16<64, 2, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds64);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16<128, 2, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds128);
     attr_done = true;
   }
-  const bool pb1 = CT == 64 && (d->tile == 2 || (d->tile == 0 && d->Cin >= 128));
+  const int variant = CT == 128 ? 1 : (d->tile ? d->tile : (d->Cin >= 128 ? 2 : C3_AUTO_SHORTK));
+  if (variant == 3) { a.TBY = (d->H + 31) / 32; }
+  const long long ntiles = (long long)d->N * a.TBY * a.TBX * a.nct;
+  BEVF_REQUIRE(ntiles < (1ll << 31), "conv3x3_bf16: too many tiles");
   const dim3 grid((unsigned)ntiles), block(256);
-  if (CT == 128) hipLaunchKernelGGL((conv3x3_bf16<128, 2>), grid, block, lds128, st, a);
-  else if (pb1) hipLaunchKernelGGL((conv3x3_bf16<64, 1>), grid, block, lds64s, st, a);
-  else hipLaunchKernelGGL((conv3x3_bf16<64, 2>), grid, block, lds64, st, a);
+  if (CT == 128) hipLaunchKernelGGL((conv3x3_bf16<128, 2, 16>), grid, block, lds128, st, a);
+  else if (variant == 3) hipLaunchKernelGGL((conv3x3_bf16<64, 1, 32>), grid, block, lds64t, st, a);
+  else if (variant == 2) hipLaunchKernelGGL((conv3x3_bf16<64, 1, 16>), grid, block, lds64s, st, a);
+  else hipLaunchKernelGGL((conv3x3_bf16<64, 2, 16>), grid, block, lds64, st, a);
   return bevf_check_launch("bevf_conv3x3_bf16");
 }

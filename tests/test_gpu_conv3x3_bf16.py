@@ -69,7 +69,7 @@ def test_conv3x3_bf16_against_fp64(gpu, N, H, W, cin, cout, res, relu, x_cs, y_c
         ref = F.relu(ref)
     got = run(x, w, scale, shift, rs, relu, x_cs, y_cs)
     assert rel_err(got, ref.float()) <= 4e-3                  # exact products, fp32 accumulate, one bf16 rounding at the store
-    for tile in (1, 2):                                       # the buffering variants run the same arithmetic in the same order
+    for tile in (1, 2, 3):                                    # the buffering / block-height variants run the same arithmetic in the same order
         assert torch.equal(run(x, w, scale, shift, rs, relu, x_cs, y_cs, tile=tile), got), tile
     # the kernel it replaces on the same operands: both round the same fp32-level value to bf16
     y2 = torch.zeros(N * H * W * cout, dtype=BF, device=gpu)
@@ -91,7 +91,7 @@ def test_conv3x3_bf16_exact_on_integer_data(gpu, N, H, W, cin, cout):
     w = torch.randint(-1, 2, (cout, cin, 3, 3), generator=g).float()
     ref = F.conv2d(x.double(), w.double(), None, 1, 1)
     assert float(ref.abs().max()) <= 256                      # integers up to 256 are bf16 numbers
-    for tile in (1, 2):                                       # two patch buffers / one (the high-occupancy variant of 64-channel tiles)
+    for tile in (1, 2, 3):                                    # two patch buffers / one (4 workgroups per CU) / one with 32-row blocks
         got = run(x, w, None, None, None, False, tile=tile)
         assert torch.equal(got.double(), ref), tile
 
