@@ -93,7 +93,7 @@ def parse_args(argv=None):
     ap.add_argument("--extras", choices=["auto", "all", "none"], default="auto",
                     help="extra.configs legs after the headline: auto = configs 3 (bf16), 5 (bf16) and 4 (train) at N=1, "
                          "the data-parallel training leg only at N>1 (it is the one with a collective); none = headline only")
-    ap.add_argument("--extra-steps", type=int, default=4)
+    ap.add_argument("--extra-steps", type=int, default=8)
     return ap.parse_args(argv)
 
 
@@ -546,7 +546,7 @@ def main():
         if mode == "train":
             ctx["inputs"].drop()
         try:
-            rec, _ = run_leg(config, dtype, mode, batch, args.extra_steps, 2, ctx, conv=conv_override[0] if conv_override else args.conv)
+            rec, _ = run_leg(config, dtype, mode, batch, args.extra_steps, 3, ctx, conv=conv_override[0] if conv_override else args.conv)
             if conv_override:
                 rec["conv_kernels"] = conv_override[0]
         except Exception as e:                               # the headline stays; the failure is recorded AND reflected in the status at N > 1
