@@ -52,12 +52,25 @@ __global__ __launch_bounds__(256) void bilinear_nhwc(const T* __restrict__ x, T*
                                                       long long total) {
   constexpr int V = vec16<T>::N;
   const int cv = C / V;
+  const bool small = total < (1ll << 31);                        // 32-bit index arithmetic (three 64-bit divisions were most of the kernel's VALU)
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % cv) * V;
-    long long pix = i / cv;
-    const int ow = (int)(pix % Wo);
-    const long long t = pix / Wo;
-    const int oh = (int)(t % Ho), b = (int)(t / Ho);
+    int c, ow, oh, b;
+    long long pix;
+    if (small) {
+      const unsigned u = (unsigned)i, up = u / (unsigned)cv, ut = up / (unsigned)Wo;
+      c = (int)(u - up * (unsigned)cv) * V;
+      ow = (int)(up - ut * (unsigned)Wo);
+      b = (int)(ut / (unsigned)Ho);
+      oh = (int)(ut - (unsigned)b * (unsigned)Ho);
+      pix = up;
+    } else {
+      c = (int)(i % cv) * V;
+      pix = i / cv;
+      ow = (int)(pix % Wo);
+      const long long t = pix / Wo;
+      oh = (int)(t % Ho);
+      b = (int)(t / Ho);
+    }
     int h0, h1, w0, w1;
     float lh0, lh1, lw0, lw1;
     lin_coord(oh, sh, Hi, h0, h1, lh0, lh1);

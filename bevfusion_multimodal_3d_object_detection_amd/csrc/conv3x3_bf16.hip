@@ -224,8 +224,14 @@ __global__ __launch_bounds__(256, (C3Geo<CT, PB, BH>::WG_PER_CU)) void conv3x3_b
     // patch piece in each of the D steps whose tap is < 6; after tap 8 that also covers the whole next patch chunk
     constexpr int cnt = [] {
       int c = (D - 1) * FPW;
-      if (PB == 2)
+      if (PB == 2) {
         for (int u = 0; u < D; ++u) c += ((t - u + 9) % 9) < PPW ? 1 : 0;
+        // tap 8 must ALSO leave the next chunk's whole patch landed: nothing may stay in flight but what was issued after its last
+        // piece (tap PPW-1), i.e. the filters of taps PPW .. 8.  (With a ring deeper than that the first count alone let patch pieces
+        // fly across the chunk boundary: wrong pixels at full size only, where the DMA queue is long -- caught by the batch-invariance
+        // test of config 5, not by the small-shape tests.)
+        if (t == 8 && c > (9 - PPW) * FPW) c = (9 - PPW) * FPW;
+      }
       return c;
     }();
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(cnt) : "memory");
