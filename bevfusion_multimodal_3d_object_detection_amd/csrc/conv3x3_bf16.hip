@@ -26,6 +26,7 @@
 
 namespace {
 
+constexpr bool C3_AUTO_PERSIST = false;                    // `tile = 0` takes the persistent kernel (tile = 4 forces it)
 constexpr int C3_AUTO_SHORTK = 1;                         // what `tile = 0` means for 64-channel tiles with Cin < 128 (1 | 2 | 3)
 
 struct C3Args {
@@ -321,6 +322,272 @@ __global__ __launch_bounds__(256, (C3Geo<CT, PB, BH>::WG_PER_CU)) void conv3x3_b
   }
 }
 
+// ---- persistent form (two patch buffers, 16-row blocks): a workgroup walks a list of tiles and the DMA schedule simply runs on ---------
+// In-kernel stamps on layer1 (64 -> 64, K = 576): a tile has 4.6k cycles of MFMA work per wave and lives 29k -- 8.3k waiting for its first
+// patch and residual (HBM), 15k in the K loop, 6k in the epilogue until its stores are acknowledged; occupancy (2-4 workgroups per CU) cannot
+// cover that, and a bigger tile changes nothing.  Here the schedule of conv3x3_bf16 is not cut at the tile boundary: in a tile's LAST chunk
+// the "next chunk" patch pieces are chunk 0 of the NEXT tile, the filter look-ahead runs on into the next tile's first steps, the residual is
+// requested at the start of the last chunk (64-channel tiles) and the epilogue's stores drain under the next tile's first steps.  The waits
+// stay exact counts: loads, DMAs and stores retire in order, so a wait may leave in flight whatever was issued after the filters it names --
+// the residual loads in the last chunk's first D steps, the previous tile's stores in a tile's first D-1 steps.
+// Each XCD owns a contiguous eighth of the tile list and its workgroups sweep it side by side (neighbouring tiles share halo rows in L2).
+template <int CT>
+__global__ __launch_bounds__(256, 2) void conv3x3_bf16_persist(const C3Args p, const int ntiles) {
+  using Geo = C3Geo<CT, 2, 16>;
+  constexpr int C3_PATCH_BYTES = Geo::PATCH_BYTES;
+  constexpr int WN = Geo::WN, MT = Geo::MT, NT = Geo::NT, WSTEP = Geo::WSTEP, RB = Geo::RB, D = RB - 1;
+  constexpr int NSH = 4, PPW = Geo::PPW, FPW = (CT / 16) / NSH;
+  constexpr bool RES_LATE = CT == 64;                              // residual requested at the start of the last chunk (MT*NT loads per wave)
+  constexpr int NRES = MT * NT, NST = MT * NT;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* const patch = lds;
+  char* const ring = lds + 2 * C3_PATCH_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN, role = wave;
+  const int NCH = p.Cin >> 5, S = 9 * NCH;
+  const int nsp = p.N * p.TBY * p.TBX;
+
+  // ---- this workgroup's tiles: XCD x = blockIdx & 7 owns tiles [start, start + len); its gx workgroups take start + li, start + li + gx, ..
+  const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+  const int gx = ((int)gridDim.x + 7 - xcd) >> 3;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7;
+  const int t_end = xcd * q8 + (xcd < r8 ? xcd : r8) + q8 + (xcd < r8 ? 1 : 0);
+  int tile = xcd * q8 + (xcd < r8 ? xcd : r8) + li;
+  if (tile >= t_end) return;                                        // (workgroup-uniform; before any barrier)
+  struct Tile { int ct, n, by, bx; };
+  auto decode = [&](int t) {
+    Tile r;
+    r.ct = t / nsp;
+    int sp = t - r.ct * nsp;
+    r.bx = sp % p.TBX;
+    sp /= p.TBX;
+    r.by = sp % p.TBY;
+    r.n = sp / p.TBY;
+    return r;
+  };
+
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)kOob, 0x00020000);
+  auto patch_dma = [&](const Tile& T, unsigned soff, int buf, int j0, int j1, bool live) {
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    const int iy0 = 16 * T.by - 1, ix0 = 16 * T.bx - 1;
+#pragma unroll
+    for (int j = j0; j < j1; ++j) {
+      const int i = (NSH * j + role) * 64 + l;
+      const int pix = i >> 2, kg = (i & 3) ^ (((pix >> 2) & 1) << 1);
+      const int py = (pix * 3277) >> 16, px = pix - py * C3_PITCH;
+      const int iy = iy0 + py, ix = ix0 + px;
+      const bool ok = live && px < C3_PW && py < Geo::PH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const unsigned voff = ok ? (unsigned)((((T.n * p.H + iy) * p.W + ix) * p.x_cs + kg * 8) * 2) : kOob;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rsx, (__attribute__((address_space(3))) void*)(patch + buf * C3_PATCH_BYTES + (NSH * j + role) * 1024), 16, voff, soff, 0, 0);
+    }
+  };
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wp), 0, (int)p.wbytes, 0x00020000);
+  const unsigned w_lane = (unsigned)(lane * 16);
+  auto ring_dma = [&](unsigned wofs, int slot) {                    // wofs: byte offset of the step's filter image (past the end: zeros)
+#pragma unroll
+    for (int i = 0; i < FPW; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rsw, (__attribute__((address_space(3))) void*)(ring + slot * WSTEP + (role + NSH * i) * 1024), 16, w_lane,
+          wofs + (unsigned)((role + NSH * i) * 1024), 0, 0);
+  };
+
+  const int col = lane & 15, kgl = lane >> 4;
+  int xa[3][2];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const int px = kw + col;
+      xa[kw][par] = wm * MT * (C3_PITCH * 64) + px * 64 + ((kgl ^ ((par ^ ((px >> 2) & 1)) << 1)) << 4);
+    }
+  const int wa = 2 * C3_PATCH_BYTES + wn * 4096 + lane * 16;
+
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)kOob, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, (int)kOob, 0x00020000);
+
+  // ---- prologue of the FIRST tile only: filters of its steps 0 .. D-1, patch chunk 0 ------------------------------------------------
+  Tile cur = decode(tile);
+  int nxt_id = tile + gx;
+  Tile nxt = decode(nxt_id < t_end ? nxt_id : tile);
+  bool has_next = nxt_id < t_end;
+  const unsigned wslab = (unsigned)S * (unsigned)WSTEP;             // bytes of one channel tile's filters
+  unsigned wofs = (unsigned)cur.ct * wslab;                         // look-ahead cursor: where the filters of step (current + D) are
+  int ahead_left = S;                                               // steps left in the cursor's tile
+#pragma unroll
+  for (int s = 0; s < D; ++s) {
+    ring_dma(wofs, s);
+    wofs += WSTEP;
+  }
+  ahead_left -= D;
+  patch_dma(cur, 0, 0, 0, PPW, true);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+  int slot = 0;
+  int pbuf = 0;                                                     // patch buffer of the current chunk (runs on across tiles)
+  f32x4 acc[NT][MT];
+  u32x2 rv[RES_LATE ? MT : 1][NT];
+  // per-tile output addressing
+  int co0, ox, oy0;
+  unsigned pixel0;
+  auto out_ok = [&](int mt) { return ox < p.W && oy0 + mt < p.H; };
+  auto load_res = [&](int mt, u32x2 (&dst)[NT]) {
+    const unsigned ro = out_ok(mt) ? ((pixel0 + (unsigned)(mt * p.W)) * (unsigned)p.res_cs + (unsigned)co0) * 2u : kOob;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) dst[nt] = __builtin_amdgcn_raw_buffer_load_b64(rsr, ro, (unsigned)(nt * 32), 0);
+  };
+
+  // one step; AFTER = first chunk of a tile that follows an epilogue (its NST stores are still draining), LASTC = the tile's last chunk
+  auto step = [&](auto tc, auto livec, auto afterc, auto lastc, const Tile& ptile, const unsigned psoff, const bool plive) {
+    constexpr int t = decltype(tc)::value, kh = t / 3, kw = t % 3;
+    constexpr bool AFTER = decltype(afterc)::value, LASTC = decltype(lastc)::value;
+    {
+      int ns = slot + D;
+      ns = ns >= RB ? ns - RB : ns;
+      ring_dma(wofs, ns);
+      wofs += WSTEP;
+      if (--ahead_left == 0) {                                      // the cursor enters the next tile (or runs off the list: zeros)
+        wofs = has_next ? (unsigned)nxt.ct * wslab : p.wbytes;
+        ahead_left = has_next ? S : (1 << 30);
+      }
+    }
+    if constexpr (t < PPW) patch_dma(ptile, psoff, pbuf ^ 1, t, t + 1, plive);
+    if constexpr (RES_LATE && LASTC && t == 0) {
+      if (p.res) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) load_res(mt, rv[mt]);
+      } else {                                                      // keep the queue's shape (the counts below are compile-time)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) rv[mt][nt] = __builtin_amdgcn_raw_buffer_load_b64(rsr, kOob, 0, 0);
+      }
+    }
+    constexpr int LIVE = decltype(livec)::value;
+    if constexpr (LIVE > 0) {
+      bf16x8 wf[NT], xf[LIVE];
+      const char* wb = lds + wa + slot * WSTEP;
+      const char* pb = patch + pbuf * C3_PATCH_BYTES;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) wf[nt] = *reinterpret_cast<const bf16x8*>(wb + nt * 1024);
+#pragma unroll
+      for (int mt = 0; mt < LIVE; ++mt)
+        xf[mt] = *reinterpret_cast<const bf16x8*>(pb + xa[kw][(mt + kh) & 1] + (mt + kh) * (C3_PITCH * 64));
+#pragma unroll
+      for (int mt = 0; mt < LIVE; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+    }
+    slot = slot + 1 == RB ? 0 : slot + 1;
+    constexpr int cnt = [] {
+      int c = (D - 1) * FPW;
+      for (int u = 0; u < D; ++u) c += ((t - u + 9) % 9) < PPW ? 1 : 0;
+      if (t == 8 && c > (9 - PPW) * FPW) c = (9 - PPW) * FPW;      // the next chunk's (or tile's) patch has landed
+      // in flight by right: what was issued AFTER the filters of step s + 1 (which left first thing in step t + 1 - D of this chunk)
+      if (RES_LATE && LASTC && t <= D - 1 && t != 8) c += NRES;     // the residual loads of step 0
+      if (AFTER && t <= D - 2 && t != 8) c += NST;                  // the previous tile's stores
+      return c > 63 ? 63 : c;
+    }();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(cnt) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
+  using T3 = std::integral_constant<int, 3>; using T4 = std::integral_constant<int, 4>; using T5 = std::integral_constant<int, 5>;
+  using T6 = std::integral_constant<int, 6>; using T7 = std::integral_constant<int, 7>; using T8 = std::integral_constant<int, 8>;
+  auto chunk = [&](auto lv, auto afterc, auto lastc, const Tile& ptile, unsigned psoff, bool plive) {
+    step(T0{}, lv, afterc, lastc, ptile, psoff, plive); step(T1{}, lv, afterc, lastc, ptile, psoff, plive);
+    step(T2{}, lv, afterc, lastc, ptile, psoff, plive); step(T3{}, lv, afterc, lastc, ptile, psoff, plive);
+    step(T4{}, lv, afterc, lastc, ptile, psoff, plive); step(T5{}, lv, afterc, lastc, ptile, psoff, plive);
+    step(T6{}, lv, afterc, lastc, ptile, psoff, plive); step(T7{}, lv, afterc, lastc, ptile, psoff, plive);
+    step(T8{}, lv, afterc, lastc, ptile, psoff, plive);
+    pbuf ^= 1;
+  };
+  using TT = std::true_type;
+  using FF = std::false_type;
+  bool first_tile = true;
+  for (;;) {
+    co0 = cur.ct * CT + wn * 64 + 4 * kgl;
+    ox = 16 * cur.bx + col;
+    oy0 = 16 * cur.by + wm * MT;
+    pixel0 = (unsigned)((cur.n * p.H + oy0) * p.W + ox);
+    int mt_live = p.H - oy0;
+    mt_live = mt_live < 0 ? 0 : (mt_live > MT ? MT : mt_live);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto kloop = [&](auto lv) {
+      for (int c = 0; c < NCH; ++c) {
+        const bool lastc = c + 1 == NCH, after = c == 0 && !first_tile;
+        // the patch that streams in under this chunk: the next chunk of this tile, or chunk 0 of the next tile
+        const Tile& ptile = lastc ? nxt : cur;
+        const unsigned psoff = lastc ? 0u : (unsigned)((c + 1) * 64);
+        const bool plive = lastc ? has_next : true;
+        if (lastc) { if (after) chunk(lv, TT{}, TT{}, ptile, psoff, plive); else chunk(lv, FF{}, TT{}, ptile, psoff, plive); }
+        else       { if (after) chunk(lv, TT{}, FF{}, ptile, psoff, plive); else chunk(lv, FF{}, FF{}, ptile, psoff, plive); }
+      }
+    };
+    kloop(std::integral_constant<int, MT>{});                      // (no dead-row specialisation here: every extra copy of the loop cost registers)
+    (void)mt_live;
+
+    // ---- epilogue of this tile (its stores drain under the next tile's first steps) ----------------------------------------------
+    f32x4 sc[NT], sh[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      sc[nt] = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + co0 + nt * 16) : f32x4{1.f, 1.f, 1.f, 1.f};
+      sh[nt] = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + co0 + nt * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    constexpr int RD = RES_LATE ? 1 : 4;
+    u32x2 rq[RD][NT];
+    if constexpr (!RES_LATE) {
+      if (p.res) {
+#pragma unroll
+        for (int mt = 0; mt < RD; ++mt) load_res(mt, rq[mt]);
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const unsigned yo = out_ok(mt) ? ((pixel0 + (unsigned)(mt * p.W)) * (unsigned)p.y_cs + (unsigned)co0) * 2u : kOob;
+      u32x2 rr[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) rr[nt] = RES_LATE ? rv[RES_LATE ? mt : 0][nt] : rq[mt % RD][nt];
+      if constexpr (!RES_LATE) {
+        if (p.res && mt + RD < MT) load_res(mt + RD, rq[mt % RD]);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = fmaf(acc[nt][mt][j], sc[nt][j], sh[nt][j]);
+        if (p.res) {
+          const bf16x4 r4 = __builtin_bit_cast(bf16x4, rr[nt]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] += (float)r4[j];
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
+        }
+        bf16x4 ob;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ob[j] = (__bf16)o[j];
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), rsy, yo, (unsigned)(nt * 32), 0);
+      }
+    }
+    if (!has_next) break;
+    first_tile = false;
+    tile = nxt_id;
+    cur = nxt;
+    nxt_id = tile + gx;
+    has_next = nxt_id < t_end;
+    nxt = decode(has_next ? nxt_id : tile);
+  }
+}
+
 // OHWI bf16 filters [Cout][3][3][Cin] -> [ct][chunk][tap][CT/16][lane][8]: element j of lane (m = lane & 15, kg = lane >> 4)
 // of fragment nt is w[ct*CT + nt*16 + m][tap][chunk*32 + kg*8 + j]
 __global__ __launch_bounds__(256) void conv3x3_pack(const unsigned short* __restrict__ w, unsigned short* __restrict__ out, int Cout,
@@ -409,11 +676,23 @@ extern "C" int bevf_conv3x3_bf16(const bevf_conv_desc* d, void* stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16<128, 2, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds128);
     attr_done = true;
   }
-  const int variant = CT == 128 ? 1 : (d->tile ? d->tile : (d->Cin >= 128 ? 2 : C3_AUTO_SHORTK));
+  const int variant = CT == 128 ? 1 : ((d->tile && d->tile != 4) ? d->tile : (d->Cin >= 128 ? 2 : C3_AUTO_SHORTK));
   if (variant == 3) { a.TBY = (d->H + 31) / 32; }
   const long long ntiles = (long long)d->N * a.TBY * a.TBX * a.nct;
   BEVF_REQUIRE(ntiles < (1ll << 31), "conv3x3_bf16: too many tiles");
   const dim3 grid((unsigned)ntiles), block(256);
+  if (CT == 64 && (d->tile == 4 || (d->tile == 0 && C3_AUTO_PERSIST && d->Cin < 128))) {                // persistent form (two patch buffers, 16-row blocks)
+    static bool pattr = false;
+    if (!pattr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_persist<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds64);
+      pattr = true;
+    }
+    a.TBY = (d->H + 15) / 16;
+    const long long nt16 = (long long)d->N * a.TBY * a.TBX * a.nct;
+    const dim3 pgrid((unsigned)(nt16 < 512 ? nt16 : 512));          // 2 workgroups per CU
+    hipLaunchKernelGGL((conv3x3_bf16_persist<64>), pgrid, block, lds64, st, a, (int)nt16);
+    return bevf_check_launch("bevf_conv3x3_bf16");
+  }
   if (CT == 128) hipLaunchKernelGGL((conv3x3_bf16<128, 2, 16>), grid, block, lds128, st, a);
   else if (variant == 3) hipLaunchKernelGGL((conv3x3_bf16<64, 1, 32>), grid, block, lds64t, st, a);
   else if (variant == 2) hipLaunchKernelGGL((conv3x3_bf16<64, 1, 16>), grid, block, lds64s, st, a);
