@@ -26,6 +26,7 @@
 
 namespace {
 
+constexpr bool C3_AUTO_WIDE64 = true;                      // `tile = 0` with Cin = 64 takes the one-image kernel (tile = 5 forces it)
 constexpr bool C3_AUTO_PERSIST = false;                    // `tile = 0` takes the persistent kernel (tile = 4 forces it)
 constexpr int C3_AUTO_SHORTK = 1;                         // what `tile = 0` means for 64-channel tiles with Cin < 128 (1 | 2 | 3)
 
@@ -319,6 +320,155 @@ __global__ __launch_bounds__(256, (C3Geo<CT, PB, BH>::WG_PER_CU)) void conv3x3_b
   if (p.stamps) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (diagnostic: the stores have been acknowledged)
     stamp(3);
+  }
+}
+
+// ---- Cin = 64 (ResNet layer1): both 32-channel halves of the patch in ONE image, fetched as whole 128-byte lines ---------------------
+// Hypothesis behind it: layer1 is bound by a throughput between L2 and the CU (3.1c); its patch DMA asks for 64 of every pixel's 128 bytes
+// per chunk, i.e. 16 half-used cache lines per instruction, and the other halves a microsecond later.  Here a pixel's 128 bytes sit
+// together in LDS ([pixel][2 halves][4 x 16 B], 46 KB, one buffer), every DMA piece is 8 pixels x 128 contiguous bytes, the whole patch is
+// requested in the prologue and the K loop issues filter DMA only.  Price: 128-byte pixel pitch -> the x-fragment reads are 2-way bank
+// conflicts (16 lanes over 8 distinct 16-byte slots of each 128-byte half-window).  Same arithmetic in the same order as the other variants.
+template <int CT>
+__global__ __launch_bounds__(256, 2) void conv3x3_bf16_wide64(const C3Args p) {
+  static_assert(CT == 64, "64 output channels per workgroup");
+  constexpr int MT = 4, NT = 4, WSTEP = CT * 64, RB = 8, D = RB - 1, NSH = 4, FPW = 1;
+  constexpr int PH = 18, PIXB = 128, ROWB = C3_PITCH * PIXB;        // 2560 bytes per patch row
+  constexpr int PPW = (PH * ROWB + 4095) / 4096;                    // DMA pieces per wave: 12
+  constexpr int PATCH_BYTES = 4 * PPW * 1024;                       // 49152
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* const patch = lds;
+  char* const ring = lds + PATCH_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave, role = wave;
+  const int S = 18;
+  const int nsp = p.N * p.TBY * p.TBX;
+  const int sid = xcd_remap(blockIdx.x, gridDim.x);
+  const int ct = sid / nsp;
+  int sp = sid - ct * nsp;
+  const int bx = sp % p.TBX;
+  sp /= p.TBX;
+  const int by = sp % p.TBY, n = sp / p.TBY;
+
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)kOob, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wp), 0, (int)p.wbytes, 0x00020000);
+  const unsigned w_lane = (unsigned)(lane * 16);
+  const unsigned w_tile = (unsigned)(ct * S) * (unsigned)WSTEP;
+  auto ring_dma = [&](int step, int slot) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(ring + slot * WSTEP + role * 1024), 16, w_lane,
+                                             w_tile + (unsigned)step * (unsigned)WSTEP + (unsigned)(role * 1024), 0, 0);
+  };
+  // patch: slot i = pixel i >> 3, half (i >> 2) & 1, piece (i & 3) ^ swz(pixel); swz as in the narrow image (2 * ((pixel >> 2) & 1))
+#pragma unroll
+  for (int s = 0; s < D; ++s) ring_dma(s, s);
+  {
+    const int iy0 = 16 * by - 1, ix0 = 16 * bx - 1;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int i = (NSH * j + role) * 64 + lane;
+      const int pix = i >> 3, half = (i >> 2) & 1, kg = (i & 3) ^ (((pix >> 2) & 1) << 1);
+      const int py = (pix * 3277) >> 16, px = pix - py * C3_PITCH;
+      const int iy = iy0 + py, ix = ix0 + px;
+      const bool ok = px < C3_PW && py < PH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const unsigned voff = ok ? (unsigned)((((n * p.H + iy) * p.W + ix) * p.x_cs + half * 32 + kg * 8) * 2) : kOob;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(patch + (NSH * j + role) * 1024), 16, voff, 0, 0, 0);
+    }
+  }
+  const int col = lane & 15, kgl = lane >> 4;
+  int xa[3][2];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const int px = kw + col;
+      xa[kw][par] = wm * MT * ROWB + px * PIXB + ((kgl ^ ((par ^ ((px >> 2) & 1)) << 1)) << 4);
+    }
+  const int wa = PATCH_BYTES + lane * 16;
+
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)kOob, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, (int)kOob, 0x00020000);
+  const int co0 = ct * CT + 4 * kgl;
+  const int ox = 16 * bx + col, oy0 = 16 * by + wm * MT;
+  const unsigned pixel0 = (unsigned)((n * p.H + oy0) * p.W + ox);
+  auto out_ok = [&](int mt) { return ox < p.W && oy0 + mt < p.H; };
+  u32x2 rv[MT][NT];
+  if (p.res) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const unsigned ro = out_ok(mt) ? ((pixel0 + (unsigned)(mt * p.W)) * (unsigned)p.res_cs + (unsigned)co0) * 2u : kOob;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) rv[mt][nt] = __builtin_amdgcn_raw_buffer_load_b64(rsr, ro, (unsigned)(nt * 32), 0);
+    }
+  }
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+  int slot = 0;
+  auto step = [&](auto tc, const int s, const int half) {
+    constexpr int t = decltype(tc)::value, kh = t / 3, kw = t % 3;
+    {
+      int ns = slot + D;
+      ns = ns >= RB ? ns - RB : ns;
+      ring_dma(s + D, ns);
+    }
+    bf16x8 wf[NT], xf[MT];
+    const char* wb = lds + wa + slot * WSTEP;
+    const char* pb = patch + half * 64;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wf[nt] = *reinterpret_cast<const bf16x8*>(wb + nt * 1024);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xf[mt] = *reinterpret_cast<const bf16x8*>(pb + xa[kw][(mt + kh) & 1] + (mt + kh) * ROWB);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+    slot = slot + 1 == RB ? 0 : slot + 1;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * FPW) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
+  using T3 = std::integral_constant<int, 3>; using T4 = std::integral_constant<int, 4>; using T5 = std::integral_constant<int, 5>;
+  using T6 = std::integral_constant<int, 6>; using T7 = std::integral_constant<int, 7>; using T8 = std::integral_constant<int, 8>;
+  for (int c = 0; c < 2; ++c) {
+    const int s0 = 9 * c;
+    step(T0{}, s0 + 0, c); step(T1{}, s0 + 1, c); step(T2{}, s0 + 2, c); step(T3{}, s0 + 3, c); step(T4{}, s0 + 4, c);
+    step(T5{}, s0 + 5, c); step(T6{}, s0 + 6, c); step(T7{}, s0 + 7, c); step(T8{}, s0 + 8, c);
+  }
+  f32x4 sc[NT], sh[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    sc[nt] = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + co0 + nt * 16) : f32x4{1.f, 1.f, 1.f, 1.f};
+    sh[nt] = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + co0 + nt * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const unsigned yo = out_ok(mt) ? ((pixel0 + (unsigned)(mt * p.W)) * (unsigned)p.y_cs + (unsigned)co0) * 2u : kOob;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = fmaf(acc[nt][mt][j], sc[nt][j], sh[nt][j]);
+      if (p.res) {
+        const bf16x4 r4 = __builtin_bit_cast(bf16x4, rv[mt][nt]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] += (float)r4[j];
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
+      }
+      bf16x4 ob;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ob[j] = (__bf16)o[j];
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), rsy, yo, (unsigned)(nt * 32), 0);
+    }
   }
 }
 
@@ -676,11 +826,23 @@ extern "C" int bevf_conv3x3_bf16(const bevf_conv_desc* d, void* stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16<128, 2, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds128);
     attr_done = true;
   }
-  const int variant = CT == 128 ? 1 : ((d->tile && d->tile != 4) ? d->tile : (d->Cin >= 128 ? 2 : C3_AUTO_SHORTK));
+  const int variant = CT == 128 ? 1 : ((d->tile && d->tile < 4) ? d->tile : (d->Cin >= 128 ? 2 : C3_AUTO_SHORTK));
   if (variant == 3) { a.TBY = (d->H + 31) / 32; }
   const long long ntiles = (long long)d->N * a.TBY * a.TBX * a.nct;
   BEVF_REQUIRE(ntiles < (1ll << 31), "conv3x3_bf16: too many tiles");
   const dim3 grid((unsigned)ntiles), block(256);
+  if (CT == 64 && d->Cin == 64 && (d->tile == 5 || (d->tile == 0 && C3_AUTO_WIDE64))) {      // both channel halves in one patch image
+    static bool wattr = false;
+    constexpr int ldsw = 4 * 12 * 1024 + 8 * 4096;
+    if (!wattr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_wide64<64>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsw);
+      wattr = true;
+    }
+    a.TBY = (d->H + 15) / 16;
+    const long long nt16 = (long long)d->N * a.TBY * a.TBX * a.nct;
+    hipLaunchKernelGGL((conv3x3_bf16_wide64<64>), dim3((unsigned)nt16), block, ldsw, st, a);
+    return bevf_check_launch("bevf_conv3x3_bf16");
+  }
   if (CT == 64 && (d->tile == 4 || (d->tile == 0 && C3_AUTO_PERSIST && d->Cin < 128))) {                // persistent form (two patch buffers, 16-row blocks)
     static bool pattr = false;
     if (!pattr) {

@@ -69,7 +69,7 @@ def test_conv3x3_bf16_against_fp64(gpu, N, H, W, cin, cout, res, relu, x_cs, y_c
         ref = F.relu(ref)
     got = run(x, w, scale, shift, rs, relu, x_cs, y_cs)
     assert rel_err(got, ref.float()) <= 4e-3                  # exact products, fp32 accumulate, one bf16 rounding at the store
-    for tile in (1, 2, 3, 4):                                 # the buffering / block-height / persistent variants run the same arithmetic in the same order
+    for tile in (1, 2, 3, 4, 5):                              # the buffering / block-height / persistent variants run the same arithmetic in the same order
         assert torch.equal(run(x, w, scale, shift, rs, relu, x_cs, y_cs, tile=tile), got), tile
     # the kernel it replaces on the same operands: both round the same fp32-level value to bf16
     y2 = torch.zeros(N * H * W * cout, dtype=BF, device=gpu)
@@ -91,7 +91,7 @@ def test_conv3x3_bf16_exact_on_integer_data(gpu, N, H, W, cin, cout):
     w = torch.randint(-1, 2, (cout, cin, 3, 3), generator=g).float()
     ref = F.conv2d(x.double(), w.double(), None, 1, 1)
     assert float(ref.abs().max()) <= 256                      # integers up to 256 are bf16 numbers
-    for tile in (1, 2, 3, 4):                                 # two patch buffers / one (4 workgroups per CU) / one with 32-row blocks / persistent
+    for tile in (1, 2, 3, 4, 5):                              # two patch buffers / one (4 workgroups per CU) / one with 32-row blocks / persistent
         got = run(x, w, None, None, None, False, tile=tile)
         assert torch.equal(got.double(), ref), tile
 
@@ -121,7 +121,7 @@ def test_conv3x3_bf16_variants_agree_bit_for_bit_at_full_occupancy(gpu, N, H, W,
     wp = L.conv3x3_pack_bf16(w, cout, cin)
     res = torch.randn((N * H * W * cout,), generator=g).to(BF).cuda()
     outs = []
-    for tile in (1, 2, 3, 4, 1, 4):
+    for tile in (1, 2, 3, 4, 5, 1, 4, 5):
         y = torch.empty(N * H * W * cout, dtype=BF, device=gpu)
         L.conv3x3_bf16(x, wp, None, None, y, N=N, H=H, W=W, Cin=cin, x_cs=cin, Cout=cout, y_cs=cout, relu=True, res=res, res_cs=cout, tile=tile)
         outs.append(y)

@@ -38,7 +38,7 @@ for name in names:
         L.conv2d_nhwc(x, w, sc, sh, y0, KH=3, KW=3, stride=1, pad=1, **kw)
 
     variants = {"old": old}
-    for tile, label in ((0, "auto"), (1, "pb2"), (2, "pb1"), (3, "pb1/32rows"), (4, "persistent")):
+    for tile, label in ((0, "auto"), (1, "pb2"), (2, "pb1"), (3, "pb1/32rows"), (4, "persistent"), (5, "wide64")):
         variants[label] = (lambda tl: (lambda: L.conv3x3_bf16(x, wp, sc, sh, y1, tile=tl, **kw)))(tile)
     t = {k: [] for k in variants}
     for _ in range(2):
