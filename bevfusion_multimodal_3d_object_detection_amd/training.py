@@ -279,6 +279,17 @@ class _BNState:
     __slots__ = ("mean", "invstd", "xraw", "y", "M", "C", "has_res")
 
 
+# Test instrumentation (tests/test_gpu_training.py): when a list, every train-mode forward site that applies a ReLU appends its
+# post-activation matrix (tensor [M*C], M, C) -- the decisions the hand-written backward will take -- so that the fp64 oracle can be
+# made to take the SAME decisions and whole-network gradients compared to 1e-4 instead of "up to a few ReLU flips".  None = off.
+RELU_TRACE: Optional[list] = None
+
+
+def _trace_relu(y, M: int, Cc: int) -> None:
+    if RELU_TRACE is not None and y is not None:
+        RELU_TRACE.append((y, M, Cc))
+
+
 FUSE_BN_STATS = False        # BatchNorm batch statistics from partial sums the Winograd conv epilogue leaves (no stats pass over the
                              # activation).  Built and tested, but off: time-neutral on MI355X (the epilogue is exposed time), and the
                              # sums are shifted by the RUNNING mean, so their accuracy depends on how far that is from the batch mean
@@ -330,6 +341,8 @@ def bn_train_forward(xraw, bn: nn.BatchNorm2d, M: int, Cc: int, res=None, relu=T
         for t in (bn.running_mean, bn.running_var, nbt):                 # written through raw pointers: bump the versions
             if t is not None:                                             # (the engines' repack signature looks at them)
                 torch.autograd.graph.increment_version(t)
+    if relu:
+        _trace_relu(y, M, Cc)
     s = _BNState()
     s.mean, s.invstd, s.xraw, s.y, s.M, s.C, s.has_res = mean, invstd, xraw, y, M, Cc, res is not None
     return y, s
@@ -446,6 +459,8 @@ class ConvBNLayer:
         if self.bn is None:
             y, Ho, Wo = conv_raw(x, w_ohwi, bias, N, H, W, self.cin, self.cout, self.k, self.stride, self.pad, relu=self.relu)
             self.y, self.M = y, N * Ho * Wo
+            if self.relu:
+                _trace_relu(y, self.M, self.cout)
             return y, Ho, Wo
         pivot, partials = bn_pivot_of(self.bn), None
         if pivot is not None:
@@ -472,6 +487,13 @@ class ConvBNLayer:
         xraw, _, _ = conv_raw(x, w_ohwi, bias, M, 1, 1, self.cin, self.cout, 1, 1, 0)
         _, self.bns = bn_train_forward(xraw, self.bn, M, self.cout, relu=True, apply=False)
         dev = x.device
+        if RELU_TRACE is not None:                               # (tests only: the activation this path never writes)
+            yt = _new(M * self.cout, dev)
+            _ck(_lib().bevf_bn_apply_f32(xraw.data_ptr(), self.bns.mean.data_ptr(), self.bns.invstd.data_ptr(),
+                                         self.bn.weight.data_ptr() if self.bn.weight is not None else None,
+                                         self.bn.bias.data_ptr() if self.bn.bias is not None else None, None, yt.data_ptr(), M,
+                                         self.cout, self.cout, 1, _st()), "bevf_bn_apply_f32")
+            _trace_relu(yt, M, self.cout)
         g = _new(B * self.cout, dev)
         idx = torch.empty(B * self.cout, dtype=torch.int32, device=dev)
         work = torch.empty(_lib().bevf_group_max_idx_work_bytes(B, P, self.cout), dtype=torch.uint8, device=dev)
@@ -609,6 +631,8 @@ class LinearLayer:
         y = _new(B * O, x.device)
         L.linear(x, w, self.lin.bias.detach() if self.lin.bias is not None else None, y, B, K, O, self.relu, *self.perm)
         self.x, self.y, self.B = x, y, B
+        if self.relu and self.perm == (0, 0):
+            _trace_relu(y, B, O)
         return y
 
     def backward(self, dy, sink: GradSink, need_dx=True):
@@ -999,6 +1023,7 @@ class DetectorTape:
         hid, _, _ = conv_raw(fused, w3.permute(0, 2, 3, 1).contiguous().view(-1), b3, B, Sh, Sw, w3.shape[1], w3.shape[0],
                              3, 1, 1, relu=True)
         self.head_in, self.head_hid = fused, hid
+        _trace_relu(hid, B * P, w3.shape[0])
         self.cs = [c.weight.shape[0] for c in convs1]
         self.w1 = torch.cat([c.weight.detach().reshape(c.weight.shape[0], self.hc) for c in convs1], 0).contiguous()
         b1 = torch.cat([c.bias.detach() for c in convs1], 0).contiguous()

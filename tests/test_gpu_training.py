@@ -333,34 +333,105 @@ def test_train_step_with_radar_against_oracle_autograd(gpu):
     assert _grad_check_against_oracle(model, ora, imgs, pts, radars, boxes, labels, gpu) >= 140
 
 
-def _grad_check_against_oracle(model, ora, imgs, pts, radars, boxes, labels, gpu, tol=1e-4, loose_tol=None):
-    """One forward/backward on the device model and on the oracle IN FLOAT64; every trainable parameter's gradient must agree to
-    1e-4 of the tensor's scale (+ an absolute floor of 2e-6 of the whole gradient's norm for the tensors whose true gradient is zero:
-    the conv / linear biases in front of a BatchNorm); BN running statistics to 2e-5.
-    Round 3: the earlier form compared against the FP32 oracle and allowed 2e-2 / an eighth of the tensors past
-    3e-3, blamed on ReLU / argmax flips.  A probe against fp64 autograd showed that most of that slack was the fp32 ORACLE's rounding:
-    on the camera+lidar+radar case all 144 device gradients are within 1e-4 of the fp64 truth.  Real flips do exist -- a ReLU input
-    within ~1e-6 of zero, taken the other way by a forward pass that is 3e-6-accurate, moves every upstream tensor by 0.3-2 % (seen on
-    lidar+radar at batch 2; 11 of 12 seeds scanned had at least one) -- so the whole-network check is TIGHT (tol 1e-4, no tensor may
-    miss) on the one case pinned flip-free (camera+lidar+radar, seed 123: the forward kernels are deterministic, so that is reproducible),
-    and the secondary cases (other radar fusions, frozen BatchNorm), whose job is to show that the right tensors receive gradients at
-    all, pass `tol=2e-2, loose_tol=3e-3` (at most an eighth of the tensors past loose_tol).  Holding those to 1e-4 as well needs the
-    device's ReLU decisions replayed into the oracle (not built).  The per-op backward tests hold every kernel to 2e-5 on its own."""
+class _ReluReplay:
+    """Makes the oracle take the device's ReLU decisions.  `trace` = training.RELU_TRACE of the device forward: every post-ReLU activation
+    as a pixel-major [M][C] matrix.  Inside the context an oracle ReLU of x looks up the device block that equals relu(x) to 1e-4 (the
+    device may hold several oracle calls in one matrix: the five head branches side by side, the five radar sweeps on top of each other)
+    and returns x where the DEVICE kept the element, 0 elsewhere.  Forward values stay the oracle's own fp64 ones; only the masks are
+    shared, so an element sitting within rounding of zero is no longer decided twice."""
+
+    def __init__(self, trace):
+        self.entries = [(y.detach()[:M * Cc].view(M, Cc).cpu().double(), set()) for y, M, Cc in trace]
+        self.hits, self.misses = 0, []
+
+    @staticmethod
+    def _to_matrix(x):
+        if x.dim() == 4:
+            return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1])
+        if x.dim() == 3:
+            return x.permute(0, 2, 1).reshape(-1, x.shape[1])
+        return x.reshape(x.shape[0], -1)
+
+    @staticmethod
+    def _from_matrix(m, like):
+        if like.dim() == 4:
+            n, c, h, w = like.shape
+            return m.view(n, h, w, c).permute(0, 3, 1, 2)
+        if like.dim() == 3:
+            b, c, p = like.shape
+            return m.view(b, p, c).permute(0, 2, 1)
+        return m.view(like.shape)
+
+    def _lookup(self, r):
+        M, Cc = r.shape
+        scale = float(r.max()) + 1e-300
+        for ent, used in self.entries:
+            Md, Cd = ent.shape
+            if Md % M or Cd % Cc:
+                continue
+            for rb in range(Md // M):
+                for cb in range(Cd // Cc):
+                    if (rb, cb) in used:
+                        continue
+                    blk = ent[rb * M:(rb + 1) * M, cb * Cc:(cb + 1) * Cc]
+                    if float((blk - r).abs().max()) <= 1e-4 * scale:
+                        used.add((rb, cb))
+                        return blk
+        return None
+
+    def __enter__(self):
+        import torch.nn.functional as Fn
+        self.saved = (Fn.relu, torch.relu)
+
+        def relu(x, inplace=False):
+            r = self._to_matrix(x.detach().clamp(min=0))
+            blk = self._lookup(r)
+            if blk is None:
+                self.misses.append(tuple(x.shape))
+                return x.clamp(min=0)
+            self.hits += 1
+            return x * self._from_matrix((blk > 0).to(x.dtype), x)
+        Fn.relu = relu
+        torch.relu = relu
+        return self
+
+    def __exit__(self, *exc):
+        import torch.nn.functional as Fn
+        Fn.relu, torch.relu = self.saved
+
+
+def _grad_check_against_oracle(model, ora, imgs, pts, radars, boxes, labels, gpu, tol=1e-4):
+    """One forward/backward on the device model, then on the oracle IN FLOAT64 with the device's ReLU decisions replayed into it
+    (_ReluReplay); every trainable parameter's gradient must agree to `tol` = 1e-4 of the tensor's scale (+ an absolute floor of 2e-6 of
+    the whole gradient's norm for the tensors whose true gradient is zero: the conv / linear biases in front of a BatchNorm); BN running
+    statistics to 2e-5.
+    Round 3.  The earlier form compared against the FP32 oracle with its own decisions and had to allow 2e-2 and an
+    eighth of the tensors past 3e-3.  Two things were folded into that slack: the fp32 ORACLE's rounding (against fp64 autograd all 144
+    gradients of camera+lidar+radar are within 1e-4), and real ReLU flips -- an input within ~1e-6 of zero taken the other way by a
+    forward pass that is 3e-6-accurate moves every upstream tensor by 0.3-2 % (11 of 12 seeds on lidar+radar at batch 2 had one).  With
+    the masks shared no tensor may miss.  (Max-pool / point-max argmax ties are not replayed: they need two candidates within 1e-6.)"""
     from oracle import ref_targets
+    cu = lambda t: None if t is None else t.cuda()
+    trace, saved_fuse = [], training.FUSE_POOL_BN_BACKWARD
+    training.RELU_TRACE, training.FUSE_POOL_BN_BACKWARD = trace, False       # (the fused stem block never writes its post-ReLU map)
+    try:
+        pred = model(cu(imgs), cu(pts), [r.cuda() for r in radars] if radars else None)
+    finally:
+        training.RELU_TRACE, training.FUSE_POOL_BN_BACKWARD = None, saved_fuse
+    tgt = ct.prepare_centernet_targets({"gt_boxes": boxes, "gt_labels": labels}, gpu)
+    loss = ct.CenterNetLoss()(pred, tgt)["total_loss"]
+    loss.backward()
     ora = ora.double()
     d = lambda t: None if t is None else t.double()
     tgt_ref = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in ref_targets.make_targets(boxes, labels).items()}
-    loss_ref = ref_targets.centernet_loss(ora(d(imgs), d(pts), [r.double() for r in radars] if radars else None), tgt_ref)["total_loss"]
+    with _ReluReplay(trace) as rp:
+        loss_ref = ref_targets.centernet_loss(ora(d(imgs), d(pts), [r.double() for r in radars] if radars else None), tgt_ref)["total_loss"]
+    assert not rp.misses and rp.hits >= 10, (rp.hits, rp.misses[:5])      # every oracle ReLU found its device counterpart
     loss_ref.backward()
-    cu = lambda t: None if t is None else t.cuda()
-    pred = model(cu(imgs), cu(pts), [r.cuda() for r in radars] if radars else None)
-    tgt = ct.prepare_centernet_targets({"gt_boxes": boxes, "gt_labels": labels}, gpu)
-    loss = ct.CenterNetLoss()(pred, tgt)["total_loss"]
     assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-5 * abs(float(loss_ref.detach()))
-    loss.backward()
     gref = dict(ora.named_parameters())
     gn = float(torch.sqrt(sum((p.grad ** 2).sum() for p in ora.parameters() if p.grad is not None)))
-    bad, checked, loose = [], 0, 0
+    bad, checked = [], 0
     for name, p in model.named_parameters():
         r = gref[name].grad
         if not gref[name].requires_grad:
@@ -371,10 +442,7 @@ def _grad_check_against_oracle(model, ora, imgs, pts, radars, boxes, labels, gpu
         err = float((p.grad.cpu().double() - r).abs().max())
         if err > tol * float(r.abs().max()) + 2e-6 * gn:
             bad.append((name, err, float(r.abs().max())))
-        if loose_tol is not None and err > loose_tol * float(r.abs().max()) + 2e-6 * gn:
-            loose += 1
     assert not bad, bad[:5]
-    assert loose <= max(6, checked // 8), (loose, checked)
     for (n1, b1), (n2, b2) in zip(model.named_buffers(), ora.named_buffers()):           # BN running statistics
         assert n1 == n2 and rel_err(b1.cpu().double(), b2.double()) <= 2e-5, n1
     return checked
@@ -395,7 +463,7 @@ def test_train_step_radar_max_mean_fusion(gpu, method):
     model = model.cuda().train()
     _, pts, radars = synth.frame_inputs(2, 0, 0, 0, 200, 4, 5, 20, 7, seed=124)
     boxes, labels = cases.target_inputs(cases.TRAIN_CASE)
-    n = _grad_check_against_oracle(model, ora, None, pts, radars, boxes, labels, gpu, tol=2e-2, loose_tol=3e-3)
+    n = _grad_check_against_oracle(model, ora, None, pts, radars, boxes, labels, gpu)
     assert n > 40 and not any("fusion_fc" in k for k, _ in model.named_parameters())
 
 
@@ -425,7 +493,7 @@ def test_freeze_bn_under_model_train(gpu):
     imgs, pts, _ = synth.frame_inputs(2, 2, 64, 96, 200, 4, seed=125)
     boxes, labels = cases.target_inputs(cases.TRAIN_CASE)
     before = model.camera_encoder.layer2[0].bn1.running_mean.clone()
-    _grad_check_against_oracle(model, ora, imgs, pts, None, boxes, labels, gpu, tol=2e-2, loose_tol=3e-3)
+    _grad_check_against_oracle(model, ora, imgs, pts, None, boxes, labels, gpu)
     assert model.camera_encoder.bn1.weight.grad is None and model.camera_encoder.layer3[1].bn2.bias.grad is None
     assert model.fusion.bev_fusion[1].weight.grad is not None                 # BatchNorms outside the camera encoder learn
     assert not torch.equal(before, model.camera_encoder.layer2[0].bn1.running_mean)
