@@ -54,6 +54,71 @@ __global__ __launch_bounds__(256) void resize_normalize_u8(const unsigned char* 
   out[o + 2 * plane] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)clip8(v2), 255.f), m2), s2);
 }
 
+// ---- the same resize in two passes through LDS (round 3) ----------------------------------------------------------------------
+// The one-thread-per-pixel form above redoes the horizontal pass for every output row that touches an input row (each input row
+// feeds ~2.5 output rows at a 2x down-scale) with 3 byte loads per tap: 75 uncoalesced byte loads and 75 integer MACs per output
+// pixel, 1.0 TB/s.  Here a workgroup owns RT output rows x 64 output columns: pass 1 runs Pillow's horizontal pass ONCE per
+// needed input row into an LDS tile of uint8 (exactly the intermediate image Pillow itself makes), pass 2 the vertical pass and
+// the normalisation from LDS.  Same integer arithmetic, same rounding, same clamp -> the same bits.
+constexpr int RT = 16, CT_ = 64, RMAX = 48;                          // output rows / columns per workgroup, input rows the tile may need
+
+__global__ __launch_bounds__(256) void resize_normalize_u8_tiled(const unsigned char* __restrict__ x, float* __restrict__ out,
+                                                                  int n, int H, int W, int Ho, int Wo,
+                                                                  const int* __restrict__ bh, const int* __restrict__ kh, int ksh,
+                                                                  const int* __restrict__ bv, const int* __restrict__ kv, int ksv,
+                                                                  float m0, float m1, float m2, float s0, float s1, float s2, int tilesX,
+                                                                  int tilesY) {
+  __shared__ unsigned char hbuf[RMAX][CT_][4];                       // horizontal-pass result, 3 channels (+1 pad) per pixel
+  const int tid = threadIdx.x;
+  const int tx = blockIdx.x % tilesX, ty = (blockIdx.x / tilesX) % tilesY, img = blockIdx.x / (tilesX * tilesY);
+  const int ox0 = tx * CT_, oy0 = ty * RT;
+  const int oy1 = (oy0 + RT < Ho ? oy0 + RT : Ho) - 1;
+  const int r0 = bv[2 * oy0], r1 = bv[2 * oy1] + bv[2 * oy1 + 1];  // input rows [r0, r1) feed this tile (bounds are monotonic)
+  const int nr = r1 - r0;                                            // <= RMAX (checked on the host)
+  const unsigned char* const base = x + (size_t)img * H * W * 3;
+  {                                                                  // pass 1: thread = (output column, channel-free), rows strided
+    const int c = tid & (CT_ - 1), rq = tid >> 6;                    // 4 row phases
+    const int ox = ox0 + c;
+    if (ox < Wo) {
+      const int x0 = bh[2 * ox], nx = bh[2 * ox + 1];
+      const int* const kx = kh + (size_t)ox * ksh;
+      for (int r = rq; r < nr; r += 4) {
+        const unsigned char* row = base + ((size_t)(r0 + r) * W + x0) * 3;
+        int h0 = 1 << (kPrec - 1), h1 = h0, h2 = h0;
+        for (int t = 0; t < nx; ++t) {
+          const int k = kx[t];
+          h0 += (int)row[3 * t] * k;
+          h1 += (int)row[3 * t + 1] * k;
+          h2 += (int)row[3 * t + 2] * k;
+        }
+        hbuf[r][c][0] = (unsigned char)clip8(h0);
+        hbuf[r][c][1] = (unsigned char)clip8(h1);
+        hbuf[r][c][2] = (unsigned char)clip8(h2);
+      }
+    }
+  }
+  __syncthreads();
+  const size_t plane = (size_t)Ho * Wo;
+  for (int e = tid; e < RT * CT_; e += 256) {                        // pass 2: thread = output pixel
+    const int c = e & (CT_ - 1), ry = e >> 6;
+    const int ox = ox0 + c, oy = oy0 + ry;
+    if (ox >= Wo || oy >= Ho) continue;
+    const int y0 = bv[2 * oy] - r0, ny = bv[2 * oy + 1];
+    const int* const ky = kv + (size_t)oy * ksv;
+    int v0 = 1 << (kPrec - 1), v1 = v0, v2 = v0;
+    for (int j = 0; j < ny; ++j) {
+      const int k = ky[j];
+      v0 += (int)hbuf[y0 + j][c][0] * k;
+      v1 += (int)hbuf[y0 + j][c][1] * k;
+      v2 += (int)hbuf[y0 + j][c][2] * k;
+    }
+    const size_t o = (size_t)img * 3 * plane + (size_t)oy * Wo + ox;
+    out[o] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)clip8(v0), 255.f), m0), s0);
+    out[o + plane] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)clip8(v1), 255.f), m1), s1);
+    out[o + 2 * plane] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)clip8(v2), 255.f), m2), s2);
+  }
+}
+
 // one workgroup per sweep: flags -> exclusive scan in point order -> compacted rows in `work`; then the output rows
 __global__ __launch_bounds__(1024) void lidar_filter_pad(const float* __restrict__ pts, float* __restrict__ out,
                                                           int* __restrict__ count, float* __restrict__ work,
@@ -117,6 +182,16 @@ extern "C" int bevf_resize_normalize_u8(const unsigned char* x, float* out, int 
   BEVF_REQUIRE(std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, "resize_normalize: zero std");
   const long long total = (long long)n * Ho * Wo;
   BEVF_REQUIRE((total + 255) / 256 < (1ll << 31), "resize_normalize: grid too large");
+  // two-pass tiled form when a tile of 16 output rows never needs more than RMAX input rows (down-scales up to ~2.7x; the row
+  // support is ksize_v, consecutive windows advance by the scale): RT * scale + ksize_v <= RMAX
+  const double scale_v = (double)H / Ho;
+  if (scale_v >= 1.0 && (RT - 1) * scale_v + ksize_v + 2 <= RMAX) {
+    const int tilesX = (Wo + CT_ - 1) / CT_, tilesY = (Ho + RT - 1) / RT;
+    hipLaunchKernelGGL(resize_normalize_u8_tiled, dim3((unsigned)((long long)n * tilesX * tilesY)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, out, n, H, W, Ho, Wo, bounds_h, coef_h, ksize_h, bounds_v, coef_v, ksize_v,
+                       mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], tilesX, tilesY);
+    return bevf_check_launch("bevf_resize_normalize_u8");
+  }
   hipLaunchKernelGGL(resize_normalize_u8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, out, n, H, W, Ho, Wo, bounds_h, coef_h, ksize_h, bounds_v,
                      coef_v, ksize_v, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
