@@ -149,21 +149,32 @@ __global__ __launch_bounds__(256, (C3Geo<CT, PB, BH>::WG_PER_CU)) void conv3x3_b
     }
   const int wa = PB * C3_PATCH_BYTES + wn * 4096 + lane * 16;          // + slot * WSTEP + nt * 1024
 
-  // ---- output addressing (epilogue; the residual of the 64-channel / two-buffer variant is requested up front) ------------
-  // acc[nt][mt][j] = channel ct*CT + wn*64 + nt*16 + 4*(lane>>4) + j of pixel (row wm*MT + mt, column lane&15)
-  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  // ---- output side (round 3, after layer1's in-kernel stamps and the wide64 experiment): whole 128-byte lines.  In the MFMA layout a
+  //      lane holds 4 channels of a pixel, so residual loads / output stores were 16 x 32-byte segments per instruction; that access
+  //      shape, not a latency, was what bound the short-K layers (layer1 483 -> 394 us with nothing else changed).  The epilogue
+  //      therefore transposes the accumulators through LDS in passes of 8 pixel rows (128 pixels x CT channels fp32, pixel pitch
+  //      CT*4 + 16 bytes: conflict-free 16-byte writes) and a lane then owns 8 consecutive channels of a pixel: item i of a pass =
+  //      pixel (i * 256 + tid) / (CT / 8) of the pass, channel group (i * 256 + tid) % (CT / 8); residual and output move as 16-byte
+  //      pieces, 8 (or 16) lanes per pixel line.  The 64-channel / two-buffer variant still requests its residual in the prologue. ------
+  typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
   const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)kOob, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, (int)kOob, 0x00020000);
-  const int co0 = ct * CT + wn * 64 + 4 * kgl;
-  const int ox = 16 * bx + col, oy0 = BH * by + wm * MT;
-  const unsigned pixel0 = (unsigned)((n * p.H + oy0) * p.W + ox);
-  auto out_ok = [&](int mt) { return ox < p.W && oy0 + mt < p.H; };
-  u32x2 rv[Geo::RES_EARLY ? MT : 1][NT];
-  auto load_res = [&](int mt, u32x2 (&dst)[NT]) {
-    const unsigned ro = out_ok(mt) ? ((pixel0 + (unsigned)(mt * p.W)) * (unsigned)p.res_cs + (unsigned)co0) * 2u : kOob;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) dst[nt] = __builtin_amdgcn_raw_buffer_load_b64(rsr, ro, (unsigned)(nt * 32), 0);
+  constexpr int RP = 8, NPASS = BH / RP, CG = CT / 8, IPP = RP * 16 * CG / 256;     // rows per pass, passes, channel groups, items per thread and pass
+  constexpr int TPITCH = CT * 4 + 16;
+  static_assert(RP * 16 * TPITCH <= Geo::LDS_BYTES, "transpose tile does not fit the kernel's LDS");
+  auto item_of = [&](int pass, int i, int& oy, int& ox, int& cb) {
+    const int e = i * 256 + tid, pl = e / CG;                        // pixel of the pass (row-major, 16 columns)
+    cb = ct * CT + 8 * (e - pl * CG);
+    oy = BH * by + pass * RP + (pl >> 4);
+    ox = 16 * bx + (pl & 15);
   };
+  auto res_load = [&](int pass, int i) {
+    int oy, ox, cb;
+    item_of(pass, i, oy, ox, cb);
+    const unsigned ro = (oy < p.H && ox < p.W) ? ((unsigned)((n * p.H + oy) * p.W + ox) * (unsigned)p.res_cs + (unsigned)cb) * 2u : kOob;
+    return __builtin_amdgcn_raw_buffer_load_b128(rsr, ro, 0, 0);
+  };
+  u32x4v rv[Geo::RES_EARLY ? NPASS * IPP : 1];
 
   int mt_live = p.H - (BH * by + wm * MT);                            // pixel rows of this wave inside the image (wave-uniform)
   mt_live = mt_live < 0 ? 0 : (mt_live > MT ? MT : mt_live);
@@ -185,7 +196,7 @@ __global__ __launch_bounds__(256, (C3Geo<CT, PB, BH>::WG_PER_CU)) void conv3x3_b
   if constexpr (Geo::RES_EARLY) {
     if (p.res) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) load_res(mt, rv[mt]);
+      for (int k = 0; k < NPASS * IPP; ++k) rv[k] = res_load(k / IPP, k % IPP);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -270,51 +281,53 @@ __global__ __launch_bounds__(256, (C3Geo<CT, PB, BH>::WG_PER_CU)) void conv3x3_b
   }
 
   stamp(2);
-  // ---- epilogue: folded BN, residual, ReLU, bf16x4 stores --------------------------------------------------------------------
-  f32x4 sc[NT], sh[NT];
+  // ---- epilogue: transpose through LDS, folded BN, residual, ReLU, 16-byte bf16x8 stores ----------------------------------------------
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");     // the look-ahead's last (zero-fill) DMAs still target LDS: drain before reuse
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    sc[nt] = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + co0 + nt * 16) : f32x4{1.f, 1.f, 1.f, 1.f};
-    sh[nt] = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + co0 + nt * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  // Residual rows not requested in the prologue: a ring of RD rows in flight.  (In-kernel stamps, layer3: loading a row's residual
-  // right where it is needed made the epilogue EIGHT serial HBM round trips -- hipcc cannot hoist a load above the previous row's
-  // stores, y may alias res -- 21.5k of a workgroup's 103k cycles.)
-  constexpr int RD = (Geo::RES_EARLY || Geo::WG_PER_CU == 4) ? 1 : 4;     // (the 128-register variant keeps one row: no room for a ring)
-  u32x2 rq[RD][NT];
-  if constexpr (!Geo::RES_EARLY) {
-    if (p.res) {
-#pragma unroll
-      for (int mt = 0; mt < RD; ++mt) load_res(mt, rq[mt]);
-    }
-  }
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const unsigned yo = out_ok(mt) ? ((pixel0 + (unsigned)(mt * p.W)) * (unsigned)p.y_cs + (unsigned)co0) * 2u : kOob;
-    u32x2 rr[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) rr[nt] = Geo::RES_EARLY ? rv[Geo::RES_EARLY ? mt : 0][nt] : rq[mt % RD][nt];
+  for (int pass = 0; pass < NPASS; ++pass) {
+    u32x4v rq[IPP];
     if constexpr (!Geo::RES_EARLY) {
-      if (p.res && mt + RD < MT) load_res(mt + RD, rq[mt % RD]);   // the slot just read: the row RD ahead
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      f32x4 o;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = fmaf(acc[nt][mt][j], sc[nt][j], sh[nt][j]);
       if (p.res) {
-        const bf16x4 r4 = __builtin_bit_cast(bf16x4, rr[nt]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] += (float)r4[j];
+        for (int i = 0; i < IPP; ++i) rq[i] = res_load(pass, i);    // in flight under the transpose below
+      }
+    }
+    if (pass) __syncthreads();                                       // the previous pass's reads are done
+    if ((wm * MT) / RP == pass || (MT < RP && (wm * MT) / RP == pass)) {   // this wave's rows lie in the pass (wave-uniform)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          *reinterpret_cast<f32x4*>(lds + (((wm * MT + mt) - pass * RP) * 16 + col) * TPITCH + (wn * 64 + nt * 16 + 4 * kgl) * 4) = acc[nt][mt];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < IPP; ++i) {
+      int oy, ox, cb;
+      item_of(pass, i, oy, ox, cb);
+      const int e = i * 256 + tid, pl = e / CG;
+      const char* tp = lds + pl * TPITCH + (e - pl * CG) * 32;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(tp), a1 = *reinterpret_cast<const f32x4*>(tp + 16);
+      f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, sh0 = {0.f, 0.f, 0.f, 0.f}, sh1 = sh0;
+      if (p.scale) { sc0 = *reinterpret_cast<const f32x4*>(p.scale + cb); sc1 = *reinterpret_cast<const f32x4*>(p.scale + cb + 4); }
+      if (p.shift) { sh0 = *reinterpret_cast<const f32x4*>(p.shift + cb); sh1 = *reinterpret_cast<const f32x4*>(p.shift + cb + 4); }
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { o[j] = fmaf(a0[j], sc0[j], sh0[j]); o[4 + j] = fmaf(a1[j], sc1[j], sh1[j]); }
+      if (p.res) {
+        const bf16x8 r8 = __builtin_bit_cast(bf16x8, Geo::RES_EARLY ? rv[Geo::RES_EARLY ? pass * IPP + i : 0] : rq[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] += (float)r8[j];
       }
       if (p.relu) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
+        for (int j = 0; j < 8; ++j) o[j] = fmaxf(o[j], 0.f);
       }
-      bf16x4 ob;
+      bf16x8 ob;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) ob[j] = (__bf16)o[j];
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), rsy, yo, (unsigned)(nt * 32), 0);
+      for (int j = 0; j < 8; ++j) ob[j] = (__bf16)o[j];
+      const unsigned yo = (oy < p.H && ox < p.W) ? ((unsigned)((n * p.H + oy) * p.W + ox) * (unsigned)p.y_cs + (unsigned)cb) * 2u : kOob;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, ob), rsy, yo, 0, 0);
     }
   }
   if (p.stamps) {
@@ -386,20 +399,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_wide64(const C3Args p) {
     }
   const int wa = PATCH_BYTES + lane * 16;
 
-  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  // Output side: whole 128-byte pixel lines.  The accumulators (a lane: 4 channels of one pixel per MFMA tile) are transposed through LDS
+  // after the K loop so that a lane then owns 8 consecutive channels (16 bytes of bf16) of a pixel: a wave instruction reads / writes
+  // 8 pixels x 128 contiguous bytes of the residual / the output instead of 16 x 32-byte segments.  Item i of lane l: pixel
+  // 32 i + (tid >> 3) of the 16 x 16 block (row = pixel >> 4, column = pixel & 15), channels 8 (tid & 7) ..
+  typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
   const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)kOob, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, (int)kOob, 0x00020000);
-  const int co0 = ct * CT + 4 * kgl;
-  const int ox = 16 * bx + col, oy0 = 16 * by + wm * MT;
-  const unsigned pixel0 = (unsigned)((n * p.H + oy0) * p.W + ox);
-  auto out_ok = [&](int mt) { return ox < p.W && oy0 + mt < p.H; };
-  u32x2 rv[MT][NT];
+  const int g8 = tid & 7, pq = tid >> 3;                              // channel group, pixel within a run of 32
+  const int cbase = ct * CT + 8 * g8;
+  auto item_pixel = [&](int i, int& oy, int& ox) {
+    const int pb = 32 * i + pq;
+    oy = 16 * by + (pb >> 4);
+    ox = 16 * bx + (pb & 15);
+  };
+  u32x4v rv[8];
   if (p.res) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const unsigned ro = out_ok(mt) ? ((pixel0 + (unsigned)(mt * p.W)) * (unsigned)p.res_cs + (unsigned)co0) * 2u : kOob;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) rv[mt][nt] = __builtin_amdgcn_raw_buffer_load_b64(rsr, ro, (unsigned)(nt * 32), 0);
+    for (int i = 0; i < 8; ++i) {
+      int oy, ox;
+      item_pixel(i, oy, ox);
+      const unsigned ro = (oy < p.H && ox < p.W) ? ((unsigned)((n * p.H + oy) * p.W + ox) * (unsigned)p.res_cs + (unsigned)cbase) * 2u : kOob;
+      rv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsr, ro, 0, 0);
     }
   }
   f32x4 acc[NT][MT];
@@ -441,34 +462,45 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_wide64(const C3Args p) {
     step(T0{}, s0 + 0, c); step(T1{}, s0 + 1, c); step(T2{}, s0 + 2, c); step(T3{}, s0 + 3, c); step(T4{}, s0 + 4, c);
     step(T5{}, s0 + 5, c); step(T6{}, s0 + 6, c); step(T7{}, s0 + 7, c); step(T8{}, s0 + 8, c);
   }
-  f32x4 sc[NT], sh[NT];
+  // ---- epilogue: accumulators -> LDS [pixel][64 channels fp32], pixel pitch 272 bytes (16 lanes x 16-byte writes then spread over all
+  //      banks); then per lane 8 consecutive channels of a pixel: folded BN, residual, ReLU, one 16-byte bf16x8 store ------------------
+  constexpr int TP = 272;
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");     // the look-ahead's last (zero-fill) filter DMAs still target the ring: drain
+  {
+    const int col = lane & 15, kgl = lane >> 4;
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    sc[nt] = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + co0 + nt * 16) : f32x4{1.f, 1.f, 1.f, 1.f};
-    sh[nt] = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + co0 + nt * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        *reinterpret_cast<f32x4*>(lds + ((wm * MT + mt) * 16 + col) * TP + (nt * 16 + 4 * kgl) * 4) = acc[nt][mt];
   }
+  __syncthreads();
+  f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, sh0 = {0.f, 0.f, 0.f, 0.f}, sh1 = sh0;
+  if (p.scale) { sc0 = *reinterpret_cast<const f32x4*>(p.scale + cbase); sc1 = *reinterpret_cast<const f32x4*>(p.scale + cbase + 4); }
+  if (p.shift) { sh0 = *reinterpret_cast<const f32x4*>(p.shift + cbase); sh1 = *reinterpret_cast<const f32x4*>(p.shift + cbase + 4); }
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const unsigned yo = out_ok(mt) ? ((pixel0 + (unsigned)(mt * p.W)) * (unsigned)p.y_cs + (unsigned)co0) * 2u : kOob;
+  for (int i = 0; i < 8; ++i) {
+    int oy, ox;
+    item_pixel(i, oy, ox);
+    const char* tp = lds + (32 * i + pq) * TP + g8 * 32;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(tp), a1 = *reinterpret_cast<const f32x4*>(tp + 16);
+    float o[8];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      f32x4 o;
+    for (int j = 0; j < 4; ++j) { o[j] = fmaf(a0[j], sc0[j], sh0[j]); o[4 + j] = fmaf(a1[j], sc1[j], sh1[j]); }
+    if (p.res) {
+      const bf16x8 r8 = __builtin_bit_cast(bf16x8, rv[i]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = fmaf(acc[nt][mt][j], sc[nt][j], sh[nt][j]);
-      if (p.res) {
-        const bf16x4 r4 = __builtin_bit_cast(bf16x4, rv[mt][nt]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] += (float)r4[j];
-      }
-      if (p.relu) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
-      }
-      bf16x4 ob;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) ob[j] = (__bf16)o[j];
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), rsy, yo, (unsigned)(nt * 32), 0);
+      for (int j = 0; j < 8; ++j) o[j] += (float)r8[j];
     }
+    if (p.relu) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = fmaxf(o[j], 0.f);
+    }
+    bf16x8 ob;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ob[j] = (__bf16)o[j];
+    const unsigned yo = (oy < p.H && ox < p.W) ? ((unsigned)((n * p.H + oy) * p.W + ox) * (unsigned)p.y_cs + (unsigned)cbase) * 2u : kOob;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, ob), rsy, yo, 0, 0);
   }
 }
 
