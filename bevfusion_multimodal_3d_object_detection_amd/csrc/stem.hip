@@ -912,11 +912,13 @@ __global__ __launch_bounds__(256) void stem_pool7x7_bf16v2(const float* __restri
   }
   // A-fragment addresses: k-group 2g + h of pixel q -> copy (q & 1), patch row stem_row_of(2g + h) + 2 ro, byte 8 (q >> 1).
   // Row of the odd group = row of the even one + 1, except 6|7 (next channel: + PR - 6), 20|21 (the zero group: same row, any finite data)
-  int abase[2];
+  // (the reads are inline asm: left to hipcc, pairs of them -- the two halves of a fragment, or the same half of two rows -- are fused into
+  //  ds_read2_b64, which runs at half rate and is banked mod 32: PMC showed 41 % conflict cycles.  Plain ds_read_b64 are conflict-free.)
+  unsigned abase[2];
 #pragma unroll
   for (int hf = 0; hf < 2; ++hf) {
     const int q = hf * 2 * WPX + mi * WPX + l31;
-    abase[hf] = (q & 1) * COPYB + 8 * (q >> 1);
+    abase[hf] = (unsigned)(uintptr_t)lds + (unsigned)((q & 1) * COPYB + 8 * (q >> 1));
   }
   const int hrow1 = h * RPB, hrow7 = h * (PR - 6) * RPB;
   const bool all_cols = ow0 >= 0 && ow0 + 3 * WPX + 32 <= Wo;      // every stem column the four wave tiles touch exists
@@ -972,12 +974,21 @@ __global__ __launch_bounds__(256) void stem_pool7x7_bf16v2(const float* __restri
         if (ow0 + hf * 2 * WPX >= Wo) break;                       // (uniform) nothing of this half exists
         typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
         bf16x8s afrag[NG];
-        const char* const ab = lds + abase[hf] + ro * 2 * RPB;
+        {
+          const unsigned a0 = abase[hf], a1 = a0 + (unsigned)hrow1, a7 = a0 + (unsigned)hrow7;
+          bf16x4v lo[NG], hi[NG];
+#define STEM_RD(g, base)                                                                                                            \
+          asm volatile("ds_read_b64 %0, %2 offset:%3\n\tds_read_b64 %1, %2 offset:%4"                                            \
+                       : "=&v"(lo[g]), "=&v"(hi[g])                                                                                  \
+                       : "v"(base), "n"(stem_row_of(2 * (g)) * RPB + ro * 2 * RPB), "n"(stem_row_of(2 * (g)) * RPB + ro * 2 * RPB + 8) \
+                       : "memory")
+          STEM_RD(0, a1); STEM_RD(1, a1); STEM_RD(2, a1); STEM_RD(3, a7); STEM_RD(4, a1); STEM_RD(5, a1);
+          STEM_RD(6, a1); STEM_RD(7, a1); STEM_RD(8, a1); STEM_RD(9, a1); STEM_RD(10, a0);
+#undef STEM_RD
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-          const char* ap = ab + stem_row_of(2 * g) * RPB + (g == 3 ? hrow7 : (g == 10 ? 0 : hrow1));
-          const bf16x4v lo = *reinterpret_cast<const bf16x4v*>(ap), hi = *reinterpret_cast<const bf16x4v*>(ap + 8);
-          afrag[g] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          for (int g = 0; g < NG; ++g) afrag[g] = __builtin_shufflevector(lo[g], hi[g], 0, 1, 2, 3, 4, 5, 6, 7);
         }
         f32x16 acc;
 #pragma unroll
