@@ -53,6 +53,8 @@ SHAPES = [  # N, H, W, cin, cout, res, relu, x_cs, y_cs
     (1, 40, 40, 256, 256, True, True, None, 512),
     (1, 12, 12, 768, 512, False, True, None, None),        # bev_fusion of the three-modality model
     (2, 57, 100, 64, 64, True, True, None, None),          # a layer-3-sized map: edge blocks in both directions
+    (1, 20, 24, 64, 192, True, True, 128, 256),            # Cin = 64 (the one-image kernel) with three channel tiles and channel slices
+    (1, 33, 18, 64, 128, False, True, None, None),         # Cin = 64 with a 128-channel tile (stays on the two-buffer kernel)
 ]
 
 

@@ -30,6 +30,8 @@ e1.record(); torch.cuda.synchronize()
 L.lib().bevf_debug_conv3x3_stamps(None)
 t = buf.view(-1, 4).cpu()
 t = t[t[:, 0] != 0]
+if t.shape[0] == 0:
+    sys.exit(f"{name} tile={tile}: this launch ran a kernel variant without stamps (the Cin = 64 one-image and persistent kernels); pass tile 1, 2 or 3")
 d = (t[:, 1:] - t[:, :-1]).double()
 life = (t[:, 3] - t[:, 0]).double()
 q = lambda v: [float(v.quantile(p)) for p in (0.1, 0.5, 0.9)]

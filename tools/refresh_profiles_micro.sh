@@ -1,0 +1,14 @@
+#!/bin/bash
+# Micro-benchmark evidence cited by profiles/README.md: run through gpurun, then copy gpurun_out/r03_*.txt to profiles/.
+set -e
+mkdir -p gpurun_out
+timeout -k 10 400 python tools/conv3x3_bench.py all 3 > gpurun_out/r03_conv3x3_bench.txt 2>&1
+echo "conv3x3 bench done"
+{ for lt in layer1:1 layer3:0 fusion1_c3:0; do echo "== ${lt%:*} (tile ${lt#*:})"; timeout -k 10 120 python tools/conv3x3_stamps.py ${lt%:*} ${lt#*:}; done; } > gpurun_out/r03_conv3x3_stamps.txt 2>&1
+echo "stamps done"
+{ timeout -k 10 200 python tools/frontend_bench.py 3
+  if [ -f build/old/libbevf_oldvox.so ]; then
+    echo "== round-2 voxeliser (BEVF_AB_LIB=build/old/libbevf_oldvox.so)"
+    BEVF_AB_LIB=build/old/libbevf_oldvox.so timeout -k 10 200 python tools/frontend_bench.py 3
+  fi; } > gpurun_out/r03_frontend_bench.txt 2>&1
+echo "frontend done"
