@@ -283,7 +283,8 @@ def conv3x3_wino(x: torch.Tensor, u: torch.Tensor, scale, shift, y: torch.Tensor
                  stats: Optional[torch.Tensor] = None, stats_pivot: Optional[torch.Tensor] = None, bnb: Optional[dict] = None,
                  tile: int = 0) -> None:
     """3x3 / stride 1 / pad 1 convolution as fused fp32 Winograd F(2x2,3x3); `u` from wino_filter_transform.
-    tile: 0 = the block geometry that covers the map with fewer blocks, 1 = 16x16-pixel blocks, 2 = 32x8-pixel blocks.
+    tile: 0 = the tiling that covers the batch with the fewest blocks, 1 = 16x16-pixel blocks per image, 2 = 32x8-pixel blocks per image,
+    3 / 4 = the same two block shapes over the images' rows stacked into one map (bit-identical results, fewer dead rows).
     `stats` [bevf_wino_stat_rows(N,H,W)][Cout][2]: also leave the BatchNorm partial sums of the output (training)."""
     if stats is not None and stats.numel() < lib().bevf_wino_stat_rows(N, H, W) * Cout * 2:
         raise BevfError("conv_wino: stats buffer too small")

@@ -49,6 +49,12 @@ struct WinoArgs {
   const float *bnb_x, *bnb_y, *bnb_mean, *bnb_invstd, *bnb_gamma, *bnb_beta;
   int N, H, W, Cin, x_cs, Cout, y_cs, res_cs;
   int TBY, TBX, nct;   // tile blocks per image (rows, cols), 64-channel slabs
+  // Stacked rows (HS > 0): the N images are treated as ONE map of N * HS rows -- image n at rows n*HS .. n*HS+H-1, the HS - H rows
+  // between two images dead (they read as zeros: they ARE the padding row both neighbours need) -- cut into SB block rows that
+  // ignore image boundaries.  A 57-row map then wastes 1 row in 58 instead of 7 in 64.  HS is even (a tile's 2x2 alignment inside
+  // its image, and with it every rounding, is what it is in the per-image tiling: the two are bit-identical) and > block height
+  // (a patch spans at most two images).  HS = 0: block rows per image, SB = N * TBY.
+  int HS, SB;
 };
 
 constexpr int PITCH = 36;                                      // floats per patch pixel in LDS (32 + 4 pad); 18x18 or 34x10 pixels
@@ -72,29 +78,49 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int G = p.Cin >> 3;                                     // channel groups of 8
   const int NCH = p.Cin >> 5;                                   // patch chunks of 32 channels
-  const int nsp = p.N * p.TBY * p.TBX, ntiles = nsp * p.nct;    // tile index = ct * nsp + spatial: concurrent workgroups share
+  const int nsp = p.SB * p.TBX, ntiles = nsp * p.nct;           // tile index = ct * nsp + spatial: concurrent workgroups share
                                                                 // one 64-channel slab of transformed filters (L2-resident)
   // ---- patch staging by LDS-DMA (buffer_load ... lds: an out-of-range lane writes zeros -- the pad ring, the pad slot of
   //      every pixel, the slots past the patch): instruction (4 j + wave), j < 12, fills 64 consecutive 16-byte slots;
   //      slot s = pixel s / 9, piece s % 9 (8 = pad) --------------------------------------------------------------------
   const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)kOob, 0x00020000);
-  auto make_pv = [&](int tile, unsigned (&pv)[PDMA], int& n, int& by, int& bx, int& ct) {
+  // n / rb: image and in-image row of the block's first pixel row; hw: rows after which a row index wraps into the next image
+  auto make_pv = [&](int tile, unsigned (&pv)[PDMA], int& n, int& rb, int& hw, int& bx, int& ct) {
     ct = tile / nsp;
     int sp = tile - ct * nsp;
     bx = sp % p.TBX;
     sp /= p.TBX;
-    by = sp % p.TBY;
-    n = sp / p.TBY;
-    const int iy0 = BHP * by - 1, ix0 = BWP * bx - 1;
+    int n0, r0;                                                     // image / in-image row of the patch's first row (block row - 1)
+    if (p.HS) {
+      const int s0 = BHP * sp - 1 + p.HS, q0 = s0 / p.HS;           // (+ HS: the division never sees -1)
+      n0 = q0 - 1;
+      r0 = s0 - q0 * p.HS;
+      hw = p.HS;
+      const bool top = r0 + 1 == p.HS;                              // the patch's first row is the last (dead) row of image n0
+      n = top ? q0 : n0;
+      rb = top ? 0 : r0 + 1;
+    } else {
+      n0 = sp / p.TBY;
+      rb = BHP * (sp - n0 * p.TBY);
+      r0 = rb - 1;
+      hw = 0x7fffffff;
+      n = n0;
+    }
+    const int ix0 = BWP * bx - 1;
     const bool live = tile < ntiles;
 #pragma unroll
     for (int j = 0; j < PDMA; ++j) {
       const int sl = (4 * j + wave) * 64 + lane;
       const int pix = (sl * 7282) >> 16, piece = sl - 9 * pix;                                  // sl / 9 for sl < 3072
       const int py = (pix * (GEO ? 6554 : 3641)) >> 16, px = pix - py * PWP;                    // pix / 18 (or / 10) for pix < 1024
-      const int iy = iy0 + py, ix = ix0 + px;
-      const bool ok = live && sl < PSLOTSG && piece < 8 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      pv[j] = ok ? (unsigned)((((n * p.H + iy) * p.W + ix) * p.x_cs + 4 * piece) * 4) : kOob;
+      int iy = r0 + py;
+      const int ix = ix0 + px;
+      const bool wr = iy >= hw;
+      iy -= wr ? hw : 0;
+      const int ni = n0 + (wr ? 1 : 0);
+      const bool ok = live && sl < PSLOTSG && piece < 8 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W &&
+                      (unsigned)ni < (unsigned)p.N;
+      pv[j] = ok ? (unsigned)((((ni * p.H + iy) * p.W + ix) * p.x_cs + 4 * piece) * 4) : kOob;
     }
   };
   auto patch_dma = [&](unsigned voff, unsigned soff, int buf, int j) {
@@ -139,13 +165,13 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
   // ---- prologue: first tile's patch chunk 0, B group 0, A fragments of group 0 -----------------------------------------
   int tile = blockIdx.x;
   unsigned pv[PDMA], pvl[PDMA];
-  int n, by, bx, ct;
+  int n, rb, hw, bx, ct;
   {                                                                 // filter DMA first: it flies while the slot offsets are computed
     const int ct0 = tile / nsp;
 #pragma unroll
     for (int i = 0; i < 8; ++i) dma_piece((unsigned)(ct0 * G) * (BG_FLOATS * 4), 0, i);
   }
-  make_pv(tile, pv, n, by, bx, ct);
+  make_pv(tile, pv, n, rb, hw, bx, ct);
 #pragma unroll
   for (int j = 0; j < PDMA; ++j) patch_dma(pv[j], 0, 0, j);
   // Staging schedule (filter image of group g+1 and a third of a later patch chunk per group, everything by LDS-DMA, no
@@ -260,14 +286,23 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
     // acc[f][nb][r]: tile 4 kq + r of this wave = (tile row kq>>1, tile column 4 (kq&1) + r), channel ct*64 + nb*16 + (lane&15)
     {
       // (GEO 1: tile 4 kq + r = tile row kq of the wave's four, tile column r)
-      const int oy = GEO ? 32 * by + 8 * wave + 2 * kq : 16 * by + 4 * wave + 2 * (kq >> 1), ox = GEO ? 8 * bx : 16 * bx + 8 * (kq & 1);
-      const bool interior = BHP * by + BHP <= p.H && BWP * bx + BWP <= p.W && ct * 64 + 64 <= p.Cout;
+      // this lane's two pixel rows (oy even, HS even: both in the same image); a row may be dead (below the map, or the row between
+      // two stacked images): its base offset is out of range and every access through it is dropped by the buffer hardware
+      int oy = rb + (GEO ? 8 * wave + 2 * kq : 4 * wave + 2 * (kq >> 1));
+      const int ox = GEO ? 8 * bx : 16 * bx + 8 * (kq & 1);
+      const bool wr = oy >= hw;
+      oy -= wr ? hw : 0;
+      const int nl = n + (wr ? 1 : 0);
+      const bool rok[2] = {nl < p.N && oy < p.H, nl < p.N && oy + 1 < p.H};
+      const bool interior = BWP * bx + BWP <= p.W && ct * 64 + 64 <= p.Cout;
       const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)kOob, 0x00020000);
       const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res), 0, (int)kOob, 0x00020000);
-      const unsigned y_lane = (unsigned)((((n * p.H + oy) * p.W + ox) * p.y_cs + ct * 64 + t) * 4);
-      const unsigned r_lane = (unsigned)((((n * p.H + oy) * p.W + ox) * p.res_cs + ct * 64 + t) * 4);
-      // interior tile blocks (all 16x16 pixels and all 64 channels exist): no per-element predicate at all; the scalar
-      // part of every address is an SGPR offset.  Edge blocks: out-of-range elements get an out-of-range VGPR offset.
+      const unsigned y_lane = (unsigned)((((nl * p.H + oy) * p.W + ox) * p.y_cs + ct * 64 + t) * 4);
+      const unsigned r_lane = (unsigned)((((nl * p.H + oy) * p.W + ox) * p.res_cs + ct * 64 + t) * 4);
+      const unsigned yb[2] = {rok[0] ? y_lane : kOob, rok[1] ? y_lane + (unsigned)(p.W * p.y_cs * 4) : kOob};
+      const unsigned rbs[2] = {rok[0] ? r_lane : kOob, rok[1] ? r_lane + (unsigned)(p.W * p.res_cs * 4) : kOob};
+      // interior tile blocks (all columns and all 64 channels exist; rows go by the two lane bases): no per-element predicate at
+      // all; the scalar part of every address is an SGPR offset.  Edge blocks: out-of-range elements get an out-of-range VGPR offset.
       auto emit = [&](auto interiorc) {
         constexpr bool kInt = decltype(interiorc)::value;
         float sc[4], sh[4];
@@ -279,11 +314,13 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
           sc[nb] = (p.scale && cok[nb]) ? p.scale[co] : 1.f;
           sh[nb] = (p.shift && cok[nb]) ? p.shift[co] : 0.f;
         }
-        auto live = [&](int nb, int q) {                             // q = r*4 + i*2 + j
-          return kInt || (cok[nb] && oy + ((q >> 1) & 1) < p.H && ox + 2 * (q >> 2) + (q & 1) < p.W);
+        auto colok = [&](int nb, int q) {                            // q = r*4 + i*2 + j: pixel row i, column 2r + j of the lane's 2 x 8
+          return kInt || (cok[nb] && ox + 2 * (q >> 2) + (q & 1) < p.W);
         };
-        auto soff_of = [&](int nb, int q, int cs) {                  // scalar byte offset of element q of channel block nb
-          return (unsigned)(((((q >> 1) & 1) * p.W + 2 * (q >> 2) + (q & 1)) * cs + nb * 16) * 4);
+        auto live = [&](int nb, int q) { return rok[(q >> 1) & 1] && colok(nb, q); };
+        auto vo = [&](int nb, int q, const unsigned (&base)[2]) { return colok(nb, q) ? base[(q >> 1) & 1] : kOob; };
+        auto soff_of = [&](int nb, int q, int cs) {                  // scalar byte offset of element q of channel block nb (within its row)
+          return (unsigned)(((2 * (q >> 2) + (q & 1)) * cs + nb * 16) * 4);
         };
         float rv[BNB ? 2 : 4][16];                                   // residual
         float lx[BNB ? 2 : 1][16], ly[BNB == 2 ? 2 : 1][16];         // BNB: the BatchNorm layer's raw input / its output
@@ -292,13 +329,13 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
         auto fetch = [&](int nb, int set) {                          // BNB: one channel block's operands, a block ahead of their use
 #pragma unroll
           for (int q = 0; q < 16; ++q) {
-            const unsigned vo = live(nb, q) ? y_lane : kOob;         // bnb_x / bnb_y are laid out like y (y_cs == Cout)
-            lx[set][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbx, vo, soff_of(nb, q, p.y_cs), 0));
+            const unsigned vy = vo(nb, q, yb);                       // bnb_x / bnb_y are laid out like y (y_cs == Cout)
+            lx[set][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbx, vy, soff_of(nb, q, p.y_cs), 0));
             if constexpr (BNB == 2)
-              ly[set][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rby, vo, soff_of(nb, q, p.y_cs), 0));
+              ly[set][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rby, vy, soff_of(nb, q, p.y_cs), 0));
             if constexpr (RES)
               rv[set][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                               rsr, live(nb, q) ? r_lane : kOob, soff_of(nb, q, p.res_cs), 0));
+                               rsr, vo(nb, q, rbs), soff_of(nb, q, p.res_cs), 0));
           }
         };
         if constexpr (BNB != 0) {
@@ -309,7 +346,7 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
 #pragma unroll
             for (int q = 0; q < 16; ++q)
               rv[nb][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                              rsr, live(nb, q) ? r_lane : kOob, soff_of(nb, q, p.res_cs), 0));
+                              rsr, vo(nb, q, rbs), soff_of(nb, q, p.res_cs), 0));
         }
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
@@ -357,8 +394,7 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
                     st2 = fmaf(o, (lx[set][q] - mu) * is, st2);
                   }
                 }
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rsy, live(nb, q) ? y_lane : kOob,
-                                                      soff_of(nb, q, p.y_cs), 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rsy, vo(nb, q, yb), soff_of(nb, q, p.y_cs), 0);
                 if constexpr (STATS) {
                   const float dv = live(nb, q) ? o - pvt : 0.f;
                   st1 += dv;
@@ -467,11 +503,28 @@ extern "C" int bevf_conv3x3_wino_f32(const bevf_conv_desc* d, void* stream) {
   }
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.x_cs = d->x_cs; a.Cout = d->Cout; a.y_cs = d->y_cs; a.res_cs = d->res_cs;
   a.TBY = (d->H + 15) / 16; a.TBX = (d->W + 15) / 16; a.nct = (d->Cout + 63) / 64;
-  // block geometry: 32x8-pixel blocks where they cover the map with fewer blocks (plain epilogues only: the statistics rows are per 16x16 block)
-  const long long b16 = (long long)a.TBY * a.TBX, b32 = (long long)((d->H + 31) / 32) * ((d->W + 7) / 8);
-  const bool geo1 = !d->stats && !d->bnb_x && d->tile != 1 && (b32 < b16 || d->tile == 2);
-  if (geo1) { a.TBY = (d->H + 31) / 32; a.TBX = (d->W + 7) / 8; }
-  const long long ntiles = (long long)d->N * a.TBY * a.TBX * a.nct;
+  a.HS = 0; a.SB = d->N * a.TBY;
+  // Block geometry (16x16 or 32x8 pixels) and row stacking (WinoArgs::HS): whichever covers the batch with the fewest blocks; plain
+  // epilogues only (the statistics rows are per 16x16 block of one image).  tile: 0 = auto, 1 / 2 = 16x16 / 32x8 per image,
+  // 3 / 4 = the same two over stacked rows (tests: all four are bit-identical)
+  bool geo1 = false;
+  if (!d->stats && !d->bnb_x && d->tile != 1) {
+    const int hs = d->H + 1 + ((d->H + 1) & 1);                     // even, >= H + 1
+    long long best = (long long)a.SB * a.TBX;
+    for (int cand = 1; cand < 4; ++cand) {                          // bit 0: 32x8 blocks, bit 1: stacked rows
+      const int bh = (cand & 1) ? 32 : 16, bw = (cand & 1) ? 8 : 16, tbx = (d->W + bw - 1) / bw;
+      if ((cand & 2) && (hs <= bh || (long long)d->N * hs >= (1ll << 30))) continue;
+      const long long sb = (cand & 2) ? ((long long)d->N * hs - (hs - d->H) + bh - 1) / bh : (long long)d->N * ((d->H + bh - 1) / bh);
+      const bool forced = d->tile == cand + 1;
+      if (d->tile != 0 && !forced) continue;
+      if (forced || sb * tbx < best) {
+        best = sb * tbx;
+        geo1 = cand & 1;
+        a.TBY = (d->H + bh - 1) / bh; a.TBX = tbx; a.SB = (int)sb; a.HS = (cand & 2) ? hs : 0;
+      }
+    }
+  }
+  const long long ntiles = (long long)a.SB * a.TBX * a.nct;
   BEVF_REQUIRE(ntiles < (1ll << 31), "conv_wino: too many tiles");
   hipStream_t st = static_cast<hipStream_t>(stream);
   static bool attr_done = false;

@@ -50,7 +50,11 @@ def test_filter_transform_matches_float64_host(gpu):
 @pytest.mark.parametrize("N,H,W,cin,cout,res,relu,xcs,ycs", [
     (2, 13, 21, 64, 64, False, True, 64, 64), (1, 33, 18, 96, 80, True, True, 96, 80), (1, 16, 16, 32, 64, False, False, 32, 64),
     (3, 1, 1, 64, 16, False, True, 64, 16), (1, 2, 47, 128, 320, True, False, 128, 320), (2, 31, 17, 64, 100, False, True, 160, 256),
-    (1, 50, 50, 256, 256, True, True, 768, 256), (1, 17, 64, 512, 72, False, True, 512, 72)])
+    (1, 50, 50, 256, 256, True, True, 768, 256), (1, 17, 64, 512, 72, False, True, 512, 72),
+    # several images whose rows the stacked tilings (tile 3 / 4) cut across: odd H (one dead row between images), even H (two),
+    # H just above one block height (only the 16-row blocks can stack)
+    (5, 57, 20, 64, 64, True, True, 64, 64), (4, 40, 24, 32, 128, False, True, 32, 128), (7, 17, 9, 64, 64, True, False, 64, 64),
+    (3, 34, 30, 32, 64, True, True, 96, 64)])
 def test_conv_wino_against_fp64_and_direct(gpu, N, H, W, cin, cout, res, relu, xcs, ycs):
     s = N * 1000 + H * 10 + cin
     x = synth.normal((N, cin, H, W), s + 1).relu() * 2.0
@@ -69,7 +73,7 @@ def test_conv_wino_against_fp64_and_direct(gpu, N, H, W, cin, cout, res, relu, x
     w_ohwi = _nhwc(w).view(-1).cuda()
     u = L.wino_filter_transform(w_ohwi, cout, cin)
     outs = []
-    for tile in (0, 1, 2):                                                  # auto, 16x16-pixel blocks, 32x8-pixel blocks
+    for tile in (0, 1, 2, 3, 4):                                # auto; 16x16 / 32x8-pixel blocks per image; the same over stacked rows
         y = torch.full((M * ycs,), -5.0, device=gpu)
         L.conv3x3_wino(xb.view(-1).cuda(), u, scale.cuda(), shift.cuda(), y, N=N, H=H, W=W, Cin=cin, x_cs=xcs, Cout=cout, y_cs=ycs,
                        relu=relu, res=rb, res_cs=cout if res else 0, tile=tile)
@@ -78,7 +82,7 @@ def test_conv_wino_against_fp64_and_direct(gpu, N, H, W, cin, cout, res, relu, x
         assert bool((got[:, cout:] == -5.0).all())                          # nothing written past Cout in a wider pixel
         outs.append(got)
     # the geometry changes which block a tile belongs to, not the tile's arithmetic: bit-identical results
-    assert torch.equal(outs[1], outs[2]) and torch.equal(outs[0], outs[1])
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
     yd = torch.zeros(M * ycs, device=gpu)
     L.conv2d_nhwc(xb.view(-1).cuda(), w_ohwi, scale.cuda(), shift.cuda(), yd, N=N, H=H, W=W, Cin=cin, x_cs=xcs, Cout=cout, y_cs=ycs,
                   KH=3, KW=3, stride=1, pad=1, relu=relu, res=rb, res_cs=cout if res else 0)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Fused fp32 Winograd convolution on the 3x3 / stride 1 layer shapes of config 2 at B=8 (TF direct-equivalent), with both
-block geometries (16x16-pixel and 32x8-pixel blocks; the launcher picks the one with fewer blocks)."""
+block geometries (16x16-pixel and 32x8-pixel blocks), each per image and over the images' rows stacked into one map; the launcher
+(auto) picks the tiling with the fewest blocks."""
 import os
 import sys
 
@@ -27,7 +28,7 @@ for name in names:
     r = torch.randn(N * H * W * Cout, device=dev) if res else None
     flops = 2.0 * N * H * W * Cout * 9 * Cin
     line = f"{name:8s} N={N} {H}x{W} {Cin}->{Cout}{' +res' if res else ''}:"
-    for tile, label in ((1, "16x16 blocks"), (2, "32x8 blocks")):
+    for tile, label in ((1, "16x16"), (2, "32x8"), (3, "16x16 stacked"), (4, "32x8 stacked"), (0, "auto")):
         y = torch.empty(N * H * W * Cout, device=dev)
         run = lambda: L.conv3x3_wino(x, u, sc, sh, y, N=N, H=H, W=W, Cin=Cin, x_cs=Cin, Cout=Cout, y_cs=Cout, relu=True,
                                      res=r, res_cs=Cout if res else 0, tile=tile)
@@ -41,5 +42,5 @@ for name in names:
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 10
-        line += f"  {label} {ms * 1e3:8.1f} us {flops / ms / 1e9:6.1f} TF"
+        line += f"  {label} {ms * 1e3:7.1f} us {flops / ms / 1e9:5.1f} TF"
     print(line, flush=True)
