@@ -134,6 +134,7 @@ SIGNATURES = {
     "bevf_conv3x3_pack_bf16": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 2 + [C.c_void_p]),
     "bevf_conv3x3_bf16": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "bevf_debug_conv3x3_stamps": (C.c_int, [C.c_void_p]),
+    "bevf_debug_wino_stamps": (C.c_int, [C.c_void_p]),
     "bevf_stem_pack_bf16": (C.c_int, [C.c_void_p] * 3),
     "bevf_stem_conv7x7_bf16mma": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_stem_pool_bf16mma": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p]),

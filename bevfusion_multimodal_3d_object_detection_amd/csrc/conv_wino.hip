@@ -55,6 +55,8 @@ struct WinoArgs {
   // its image, and with it every rounding, is what it is in the per-image tiling: the two are bit-identical) and > block height
   // (a patch spans at most two images).  HS = 0: block rows per image, SB = N * TBY.
   int HS, SB;
+  unsigned div_mul;    // ceil(2^32 / HS) (stacked) or ceil(2^32 / TBY) (0 for TBY = 1): row -> image by one s_mul_hi (the host checks the range)
+  unsigned long long* stamps;   // DIAG instantiations only (bevf_debug_wino_stamps): 5 x s_memtime per workgroup
 };
 
 constexpr int PITCH = 36;                                      // floats per patch pixel in LDS (32 + 4 pad); 18x18 or 34x10 pixels
@@ -65,8 +67,15 @@ constexpr int LDS_BYTES = (2 * PATCH_FLOATS + 2 * BG_FLOATS) * 4;
 
 // GEO = block geometry: 0 = 8x8 tiles (16x16 pixels; wave w: tile rows 2w, 2w+1), 1 = 16x4 tiles (32 rows x 8 columns; wave w:
 // tile rows 4w .. 4w+3) -- the host takes whichever covers the map with fewer blocks (57x100: 28 -> 26, 113x200: 104 -> 100).
-template <bool RES, bool RELU, bool STATS = false, int BNB = 0, int GEO = 0>
+template <bool RES, bool RELU, bool STATS = false, int BNB = 0, int GEO = 0, bool DIAG = false>
 __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
+  auto stamp = [&](int i) {                                         // diagnostic launches only; the buffer is read by nothing else
+    if constexpr (DIAG) {
+      if (threadIdx.x == 0)
+        p.stamps[(size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 5 + i] = __builtin_amdgcn_s_memtime();
+    }
+  };
+  stamp(0);
   constexpr int BHP = GEO ? 32 : 16, BWP = GEO ? 8 : 16;          // block height / width in pixels
   constexpr int PWP = BWP + 2, PIXG = (BHP + 2) * PWP;            // patch width, patch pixels (324 or 340)
   constexpr int PSLOTSG = PIXG * 9;
@@ -78,21 +87,23 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int G = p.Cin >> 3;                                     // channel groups of 8
   const int NCH = p.Cin >> 5;                                   // patch chunks of 32 channels
-  const int nsp = p.SB * p.TBX, ntiles = nsp * p.nct;           // tile index = ct * nsp + spatial: concurrent workgroups share
-                                                                // one 64-channel slab of transformed filters (L2-resident)
+  // grid = (TBX, SB, nct): dispatch order x, y, z = spatial blocks of one 64-channel slab first, so concurrent workgroups share one slab
+  // of transformed filters (L2-resident); no index arithmetic to decode a tile
   // ---- patch staging by LDS-DMA (buffer_load ... lds: an out-of-range lane writes zeros -- the pad ring, the pad slot of
   //      every pixel, the slots past the patch): instruction (4 j + wave), j < 12, fills 64 consecutive 16-byte slots;
   //      slot s = pixel s / 9, piece s % 9 (8 = pad) --------------------------------------------------------------------
   const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)kOob, 0x00020000);
   // n / rb: image and in-image row of the block's first pixel row; hw: rows after which a row index wraps into the next image
-  auto make_pv = [&](int tile, unsigned (&pv)[PDMA], int& n, int& rb, int& hw, int& bx, int& ct) {
-    ct = tile / nsp;
-    int sp = tile - ct * nsp;
-    bx = sp % p.TBX;
-    sp /= p.TBX;
+  // The 12 slot offsets of a wave are what stands between the workgroup's start and its first HBM request, beside fp32 MFMAs that
+  // share the vector ALU with them: 24-bit multiplies only (full rate; every factor is < 2^24: a pixel index because the tensor stays
+  // below 2 GiB with >= 32 channels of 4 bytes), no division (3D grid, one s_mul_hi for the image of a row).
+  auto make_pv = [&](unsigned (&pv)[PDMA], int& n, int& rb, int& hw, int& bx, int& ct) {
+    bx = blockIdx.x;
+    const int sp = blockIdx.y;
+    ct = blockIdx.z;
     int n0, r0;                                                     // image / in-image row of the patch's first row (block row - 1)
     if (p.HS) {
-      const int s0 = BHP * sp - 1 + p.HS, q0 = s0 / p.HS;           // (+ HS: the division never sees -1)
+      const int s0 = BHP * sp - 1 + p.HS, q0 = (int)__umulhi((unsigned)s0, p.div_mul);   // s0 / HS (+ HS: the division never sees -1)
       n0 = q0 - 1;
       r0 = s0 - q0 * p.HS;
       hw = p.HS;
@@ -100,33 +111,39 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
       n = top ? q0 : n0;
       rb = top ? 0 : r0 + 1;
     } else {
-      n0 = sp / p.TBY;
+      n0 = p.div_mul ? (int)__umulhi((unsigned)sp, p.div_mul) : sp;   // sp / TBY (TBY = 1: the multiplier 2^32 is passed as 0)
       rb = BHP * (sp - n0 * p.TBY);
       r0 = rb - 1;
       hw = 0x7fffffff;
       n = n0;
     }
     const int ix0 = BWP * bx - 1;
-    const bool live = tile < ntiles;
+    const unsigned nh0 = (unsigned)(n0 * p.H), xcs4 = (unsigned)(p.x_cs * 4);
 #pragma unroll
     for (int j = 0; j < PDMA; ++j) {
-      const int sl = (4 * j + wave) * 64 + lane;
-      const int pix = (sl * 7282) >> 16, piece = sl - 9 * pix;                                  // sl / 9 for sl < 3072
-      const int py = (pix * (GEO ? 6554 : 3641)) >> 16, px = pix - py * PWP;                    // pix / 18 (or / 10) for pix < 1024
-      int iy = r0 + py;
-      const int ix = ix0 + px;
+      const unsigned sl = (unsigned)((4 * j + wave) * 64 + lane);
+      const unsigned pix = __umul24(sl, 7282u) >> 16, piece = sl - 9u * pix;                    // sl / 9 for sl < 3072
+      const unsigned py = __umul24(pix, GEO ? 6554u : 3641u) >> 16, px = pix - __umul24(py, (unsigned)PWP);   // pix / 10 (or / 18) for pix < 1024
+      int iy = r0 + (int)py;
+      const int ix = ix0 + (int)px;
       const bool wr = iy >= hw;
       iy -= wr ? hw : 0;
-      const int ni = n0 + (wr ? 1 : 0);
-      const bool ok = live && sl < PSLOTSG && piece < 8 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W &&
-                      (unsigned)ni < (unsigned)p.N;
-      pv[j] = ok ? (unsigned)((((ni * p.H + iy) * p.W + ix) * p.x_cs + 4 * piece) * 4) : kOob;
+      const bool ok = sl < (unsigned)PSLOTSG && piece < 8u && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W &&
+                      (unsigned)(n0 + (wr ? 1 : 0)) < (unsigned)p.N;
+      const unsigned row = nh0 + (wr ? (unsigned)p.H : 0u) + (unsigned)iy;                      // image row index over the batch
+      pv[j] = ok ? __umul24(__umul24(row, (unsigned)p.W) + (unsigned)ix, xcs4) + 16u * piece : kOob;
     }
   };
-  auto patch_dma = [&](unsigned voff, unsigned soff, int buf, int j) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(patch + buf * PATCH_FLOATS + (4 * j + wave) * 256),
+  auto patch_dma_from = [&](__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, int buf, int j) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(patch + buf * PATCH_FLOATS + (4 * j + wave) * 256),
                                              16, voff, soff, 0, 0);
   };
+  auto patch_dma = [&](unsigned voff, unsigned soff, int buf, int j) { patch_dma_from(rsx, voff, soff, buf, j); };
+  // RES: in a tile's LAST chunk the "next chunk" slots have nothing to fetch; two of them (group 0's first two) then touch one 16-byte
+  // piece of every 128-byte line of this wave's residual pixels -- the data lands in the idle patch buffer and is never read, but the
+  // lines are in L2 when the epilogue asks for them ~3 groups later (the epilogue waited 4.7k cycles for HBM here: tools/wino_stamps.py)
+  const __amdgpu_buffer_rsrc_t rsr_pf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(RES ? p.res : p.x), 0, (int)kOob, 0x00020000);
+  bool pf_res = false;                                              // group 0's part of the patch comes through rsr_pf
 
   // ---- B staging by LDS-DMA: group image = 32 pieces of 1 KiB; wave w issues pieces 8w .. 8w+7 ----------------------
   // (buffer form: the per-lane part of the address is one constant VGPR, the image / piece offset a scalar -- the global
@@ -163,15 +180,14 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
   };
 
   // ---- prologue: first tile's patch chunk 0, B group 0, A fragments of group 0 -----------------------------------------
-  int tile = blockIdx.x;
   unsigned pv[PDMA], pvl[PDMA];
   int n, rb, hw, bx, ct;
   {                                                                 // filter DMA first: it flies while the slot offsets are computed
-    const int ct0 = tile / nsp;
+    const int ct0 = blockIdx.z;
 #pragma unroll
     for (int i = 0; i < 8; ++i) dma_piece((unsigned)(ct0 * G) * (BG_FLOATS * 4), 0, i);
   }
-  make_pv(tile, pv, n, rb, hw, bx, ct);
+  make_pv(pv, n, rb, hw, bx, ct);
 #pragma unroll
   for (int j = 0; j < PDMA; ++j) patch_dma(pv[j], 0, 0, j);
   // Staging schedule (filter image of group g+1 and a third of a later patch chunk per group, everything by LDS-DMA, no
@@ -191,6 +207,7 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) cols_row(r);
   int pbuf = 0;                                                     // patch buffer holding the current chunk
+  stamp(1);
 
   // one channel group (8 channels = 2 MFMA k-steps); gl = position in the 32-channel patch chunk (static)
   //   pvl / psoff: where the NEXT chunk's patch comes from (this tile's next chunk, or the next tile's chunk 0)
@@ -238,7 +255,8 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
         if (f == 0 && bnext) dma_piece(bimg, (gl + 1) & 1, k);
         if (f == 1 && k >= 4 && gl != 2) {
           constexpr int part = gl == 3 ? 0 : gl + 1;
-          patch_dma(pvl[part * 4 + (k - 4)], psoff, gl == 3 ? pbuf : pbuf ^ 1, part * 4 + (k - 4));
+          if (RES && gl == 0 && pf_res) patch_dma_from(rsr_pf, pvl[part * 4 + (k - 4)], psoff, pbuf ^ 1, part * 4 + (k - 4));
+          else patch_dma(pvl[part * 4 + (k - 4)], psoff, gl == 3 ? pbuf : pbuf ^ 1, part * 4 + (k - 4));
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -268,6 +286,22 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
       if (lastc) {                                                  // no next chunk: out-of-range VGPR offsets, the DMA writes zeros
 #pragma unroll                                                      // into the idle buffer (the SGPR offset is not range-checked)
         for (int j = 4; j < PDMA; ++j) pvl[j] = kOob;
+        if constexpr (RES) {                                        // ... except the two residual-prefetch slots (see rsr_pf)
+          pf_res = true;
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const int line = s2 * 64 + lane, pw = line >> 1;        // this wave's 64 pixels x two 128-byte halves of their 64 channels
+            const int prow = GEO ? (pw >> 3) : (pw >> 4), pcol = GEO ? (pw & 7) : (pw & 15);
+            int ry = rb + (GEO ? 8 : 4) * wave + prow;
+            const bool wr = ry >= hw;
+            ry -= wr ? hw : 0;
+            const int rn = n + (wr ? 1 : 0), rx = BWP * bx + pcol;
+            const bool ok = rn < p.N && ry < p.H && rx < p.W && ct * 64 + (line & 1) * 32 < p.Cout;
+            // (the group adds soff to every address of this part: taken off here; an offset below soff wraps out of range and that
+            //  one line is simply not prefetched)
+            pvl[4 + s2] = ok ? (unsigned)((((rn * p.H + ry) * p.W + rx) * p.res_cs + ct * 64 + (line & 1) * 32) * 4) - soff : kOob;
+          }
+        }
       }
       if (chunk + 2 >= NCH) {                                       // no chunk after next: the same for the part group 3 fetches
 #pragma unroll
@@ -281,6 +315,7 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
     }
 
     asm volatile("s_waitcnt vmcnt(0)");                             // (the last, all-out-of-range patch part: LDS is reused below)
+    stamp(2);
     if constexpr (STATS || BNB != 0) __syncthreads();              // ... by EVERY wave's zero-writing DMAs before any wave's partial sums land there
     // ---- epilogue: output transform per (tile, channel), scale/shift (+res) (+relu), store ----------------------------
     // acc[f][nb][r]: tile 4 kq + r of this wave = (tile row kq>>1, tile column 4 (kq&1) + r), channel ct*64 + nb*16 + (lane&15)
@@ -322,7 +357,7 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
         auto soff_of = [&](int nb, int q, int cs) {                  // scalar byte offset of element q of channel block nb (within its row)
           return (unsigned)(((2 * (q >> 2) + (q & 1)) * cs + nb * 16) * 4);
         };
-        float rv[BNB ? 2 : 4][16];                                   // residual
+        float rv[2][16];                                             // residual: two channel blocks in flight
         float lx[BNB ? 2 : 1][16], ly[BNB == 2 ? 2 : 1][16];         // BNB: the BatchNorm layer's raw input / its output
         const __amdgpu_buffer_rsrc_t rbx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bnb_x), 0, (int)kOob, 0x00020000);
         const __amdgpu_buffer_rsrc_t rby = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bnb_y), 0, (int)kOob, 0x00020000);
@@ -338,15 +373,16 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
                                rsr, vo(nb, q, rbs), soff_of(nb, q, p.res_cs), 0));
           }
         };
+        auto res_fetch = [&](int nb, int set) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            rv[set][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsr, vo(nb, q, rbs), soff_of(nb, q, p.res_cs), 0));
+        };
         if constexpr (BNB != 0) {
           fetch(0, 0);
-        } else if constexpr (RES) {                                  // all 64 residual loads first: one latency, hidden under
-#pragma unroll                                                       // the accumulator reads and output transforms below
-          for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-            for (int q = 0; q < 16; ++q)
-              rv[nb][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                              rsr, vo(nb, q, rbs), soff_of(nb, q, p.res_cs), 0));
+        } else if constexpr (RES) {                                  // the residual of channel blocks 0, 1 now, of 2, 3 as their sets
+          res_fetch(0, 0);                                           // free up (L2 hits: the last chunk prefetched the lines); 32
+          res_fetch(1, 1);                                           // registers instead of 64
         }
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
@@ -354,8 +390,7 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
           if constexpr (BNB != 0) {
             if (nb < 3) fetch(nb + 1, (nb + 1) & 1);
           }
-          constexpr int kSets = BNB ? 2 : 4;
-          const int set = nb % kSets;
+          const int set = nb & 1;
           float st1 = 0.f, st2 = 0.f;                                // STATS / BNB: this lane's sums for channel nb*16 + t
           const int cch = ct * 64 + nb * 16 + t;
           const float pvt = (STATS && p.pivot && cok[nb]) ? p.pivot[cch] : 0.f;
@@ -402,6 +437,9 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
                 }
               }
           }
+          if constexpr (RES && BNB == 0) {
+            if (nb < 2) res_fetch(nb + 2, set);
+          }
           if constexpr (STATS || BNB != 0) {                        // the four lane groups kq hold the same channel: fixed xor tree
             st1 += __shfl_xor(st1, 16); st2 += __shfl_xor(st2, 16);
             st1 += __shfl_xor(st1, 32); st2 += __shfl_xor(st2, 32);
@@ -413,13 +451,18 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
         }
       };
       if (interior) emit(std::true_type{}); else emit(std::false_type{});
+      if constexpr (DIAG) {
+        stamp(3);                                                   // everything issued ...
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(4);                                                   // ... and every store acknowledged
+      }
       if constexpr (STATS || BNB != 0) {                            // one partial row per tile block: the four waves' sums in fixed order
         __syncthreads();
         if (tid < 64 && ct * 64 + tid < p.Cout) {
           float a1 = 0.f, a2 = 0.f;
 #pragma unroll
           for (int w = 0; w < 4; ++w) { a1 += lds[(w * 64 + tid) * 2]; a2 += lds[(w * 64 + tid) * 2 + 1]; }
-          float* dst = p.stats + ((size_t)(tile - ct * nsp) * p.Cout + ct * 64 + tid) * 2;
+          float* dst = p.stats + ((size_t)(blockIdx.y * p.TBX + blockIdx.x) * p.Cout + ct * 64 + tid) * 2;
           dst[0] = a1;
           dst[1] = a2;
         }
@@ -459,6 +502,14 @@ __global__ __launch_bounds__(256) void wino_filter_transform(const float* __rest
 }
 
 }  // namespace
+
+static unsigned long long* g_wino_stamps = nullptr;
+// Diagnostic (tools/wino_stamps.py): buf = device buffer of 5 x 8 bytes per workgroup of the NEXT plain launches (relu, optional residual),
+// or null to stop
+extern "C" int bevf_debug_wino_stamps(void* buf) {
+  g_wino_stamps = static_cast<unsigned long long*>(buf);
+  return BEVF_OK;
+}
 
 extern "C" int bevf_wino_stat_rows(int N, int H, int W) { return N * ((H + 15) / 16) * ((W + 15) / 16); }
 
@@ -503,7 +554,7 @@ extern "C" int bevf_conv3x3_wino_f32(const bevf_conv_desc* d, void* stream) {
   }
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.x_cs = d->x_cs; a.Cout = d->Cout; a.y_cs = d->y_cs; a.res_cs = d->res_cs;
   a.TBY = (d->H + 15) / 16; a.TBX = (d->W + 15) / 16; a.nct = (d->Cout + 63) / 64;
-  a.HS = 0; a.SB = d->N * a.TBY;
+  a.HS = 0; a.SB = d->N * a.TBY; a.stamps = nullptr;
   // Block geometry (16x16 or 32x8 pixels) and row stacking (WinoArgs::HS): whichever covers the batch with the fewest blocks; plain
   // epilogues only (the statistics rows are per 16x16 block of one image).  tile: 0 = auto, 1 / 2 = 16x16 / 32x8 per image,
   // 3 / 4 = the same two over stacked rows (tests: all four are bit-identical)
@@ -525,7 +576,13 @@ extern "C" int bevf_conv3x3_wino_f32(const bevf_conv_desc* d, void* stream) {
     }
   }
   const long long ntiles = (long long)a.SB * a.TBX * a.nct;
-  BEVF_REQUIRE(ntiles < (1ll << 31), "conv_wino: too many tiles");
+  BEVF_REQUIRE(ntiles < (1ll << 31) && a.SB < 65536 && a.nct < 65536, "conv_wino: too many tiles");
+  {                                                                 // row -> image by multiply-high: exact while (rows + divisor) * divisor < 2^32
+    const unsigned long long dv = a.HS ? (unsigned long long)a.HS : (unsigned long long)a.TBY;
+    const unsigned long long top = a.HS ? (unsigned long long)a.SB * (geo1 ? 32 : 16) + dv : (unsigned long long)a.SB;
+    BEVF_REQUIRE((top + dv) * dv < (1ull << 32), "conv_wino: map too tall for the row arithmetic");
+    a.div_mul = (unsigned)(((1ull << 32) + dv - 1) / dv);
+  }
   hipStream_t st = static_cast<hipStream_t>(stream);
   static bool attr_done = false;
   if (!attr_done) {
@@ -536,7 +593,7 @@ extern "C" int bevf_conv3x3_wino_f32(const bevf_conv_desc* d, void* stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_f32<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_done = true;
   }
-  const dim3 grid((unsigned)ntiles), block(256);
+  const dim3 grid((unsigned)a.TBX, (unsigned)a.SB, (unsigned)a.nct), block(256);
   if (d->bnb_x) {
     static bool bnb_attr = false;
     if (!bnb_attr) {
@@ -557,6 +614,16 @@ extern "C" int bevf_conv3x3_wino_f32(const bevf_conv_desc* d, void* stream) {
   }
   if (d->stats) {
     hipLaunchKernelGGL((wino_f32<false, false, true>), grid, block, LDS_BYTES, st, a);
+    return bevf_check_launch("bevf_conv3x3_wino_f32");
+  }
+  if (g_wino_stamps && d->relu) {                                  // diagnostic launch: same kernel, five time stamps per workgroup
+    a.stamps = g_wino_stamps;
+    auto go = [&](auto kern) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      hipLaunchKernelGGL(kern, grid, block, LDS_BYTES, st, a);
+    };
+    if (d->res) { if (geo1) go(&wino_f32<true, true, false, 0, 1, true>); else go(&wino_f32<true, true, false, 0, 0, true>); }
+    else { if (geo1) go(&wino_f32<false, true, false, 0, 1, true>); else go(&wino_f32<false, true, false, 0, 0, true>); }
     return bevf_check_launch("bevf_conv3x3_wino_f32");
   }
   if (geo1) {

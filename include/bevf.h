@@ -329,6 +329,9 @@ int bevf_conv3x3_bf16(const bevf_conv_desc* d, void* stream);
 /* Diagnostic only (in-kernel s_memtime stamps of the kernel above: start / operands landed / K loop done / stores acknowledged per
  * workgroup, 4 x uint64 each, into `buf` for every following launch; NULL switches it off).  Never set by the product path. */
 int bevf_debug_conv3x3_stamps(void* buf);
+/* The same for bevf_conv3x3_wino_f32 (plain ReLU launches): start / first operands transformed / K loop done / epilogue issued / stores
+ * acknowledged, 5 x uint64 per workgroup. */
+int bevf_debug_wino_stamps(void* buf);
 
 /* Opt-in "f32x3" convolution: same contract as bevf_conv2d_nhwc_f32 (fp32 activations in and out, no colmax), but
  * the products run on the bf16 MFMA over an exact three-way bf16 split of both operands (six partial products,
