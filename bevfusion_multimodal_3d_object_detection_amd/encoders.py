@@ -196,7 +196,7 @@ class PointNetLiDAREncoder(_PointMLP):
         return self._engine
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if self.training and _training().any_bn_training(self):
+        if self.training and _training().wants_train_path(self):
             E.require_cuda(x)
             return _training().pointnet_train_forward(self, x)
         with torch.no_grad():
@@ -234,7 +234,7 @@ class RadarEncoder(_PointMLP):
         self._wrap = None
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if self.training and _training().any_bn_training(self):
+        if self.training and _training().wants_train_path(self):
             E.require_cuda(x)
             return _training().radar_train_forward(self, x)
         with torch.no_grad():
@@ -293,7 +293,7 @@ class MultiRadarEncoder(nn.Module):
         return self._engine
 
     def forward(self, radar_list: List[torch.Tensor]) -> torch.Tensor:
-        if self.training and _training().any_bn_training(self):
+        if self.training and _training().wants_train_path(self):
             E.require_cuda(*radar_list)
             return _training().radar_train_forward(self, list(radar_list))
         with torch.no_grad():
@@ -338,13 +338,15 @@ class VFELayer(nn.Module):
         self.bn = nn.BatchNorm1d(out_channels)
         self._engine = None
 
-    @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         E.require_cuda(x)
-        if self._engine is None:
-            object.__setattr__(self, "_engine", E.VFEEngine(self))
         B, Nv, P, Cc = x.shape                    # a 3-D input raises ValueError exactly like the reference
-        return self._engine.run(x.contiguous().float()).view(B, Nv, self.out_channels)
+        if self.training and _training().any_bn_training(self):
+            return _training().vfe_train_forward(self, x)          # batch statistics + gradients for linear / bn
+        with torch.no_grad():
+            if self._engine is None:
+                object.__setattr__(self, "_engine", E.VFEEngine(self))
+            return self._engine.run(x.contiguous().float()).view(B, Nv, self.out_channels)
 
 
 class VoxelNetLiDAREncoder(nn.Module):

@@ -112,8 +112,7 @@ def _check_eval(module: nn.Module) -> None:
                 f"{type(module).__name__} has a BatchNorm in train mode but was asked for the eval-mode kernels (BatchNorm "
                 "folded from running statistics) -- call .eval() first.  Train-mode BatchNorm, backward and optimiser run "
                 "through training.DetectorTape: the detector, ResNetCameraEncoder, PointNetLiDAREncoder, RadarEncoder / "
-                "MultiRadarEncoder, FlexibleBEVFusion and CenterNetHead reach it from forward() in train mode; VFELayer has "
-                "no train-mode path.")
+                "MultiRadarEncoder, VFELayer, FlexibleBEVFusion and CenterNetHead reach it from forward() in train mode.")
 
 
 class _Engine:

@@ -367,6 +367,68 @@ def bn_train_backward(dy, s: _BNState, bn, relu=True, need_dx=True):
     return dx, dgamma[:s.C], dbeta[:s.C]
 
 
+def group_max_with_index(a, G: int, P: int, Cc: int):
+    """max over the P rows of each of G groups of a [G*P][Cc] activation, first maximum wins -> (gmax [G*Cc], idx int32 [G*Cc])."""
+    dev = a.device
+    g = _new(G * Cc, dev)
+    idx = torch.empty(G * Cc, dtype=torch.int32, device=dev)
+    work = torch.empty(_lib().bevf_group_max_idx_work_bytes(G, P, Cc), dtype=torch.uint8, device=dev)
+    _ck(_lib().bevf_group_max_idx_f32(a.data_ptr(), g.data_ptr(), idx.data_ptr(), work.data_ptr(), G, P, Cc, _st()),
+        "bevf_group_max_idx_f32")
+    return g, idx
+
+
+def group_max_scatter(dg, idx, G: int, P: int, Cc: int):
+    """Backward of group_max_with_index: a zero [G*P][Cc] gradient with dg at the winning rows."""
+    d = _zeros(G * P * Cc, dg.device)
+    _ck(_lib().bevf_group_max_bwd_f32(dg.data_ptr(), idx.data_ptr(), d.data_ptr(), G, P, Cc, _st()), "bevf_group_max_bwd_f32")
+    return d
+
+
+def _bn_or_none(m):
+    """The reference builds `nn.BatchNorm1d(w) if use_bn else nn.Identity()` (ref src/encoders.py:258-269, 520-529)."""
+    return m if isinstance(m, nn.modules.batchnorm._BatchNorm) else None
+
+
+class PointFirstLayer:
+    """conv1 of a shared point MLP (Conv1d k=1 over <= 16 input channels) -> train-mode BatchNorm (or none: use_bn=False) -> ReLU."""
+
+    def __init__(self, conv, bn):
+        self.conv, self.bn = conv, _bn_or_none(bn)
+
+    def forward(self, rows, M: int, Cc: int):
+        self.rows, self.M, self.Cc = rows, M, Cc
+        w0 = self.conv.weight.detach().reshape(self.conv.weight.shape[0], Cc).contiguous()
+        self.c0 = c0 = w0.shape[0]
+        bias = self.conv.bias.detach() if self.conv.bias is not None else None
+        out = _new(M * c0, rows.device)
+        if self.bn is None:                                                # conv + bias + ReLU in one pass
+            L.pointwise_smallk(rows, w0, None, bias, out, M, Cc, c0, True)
+            _trace_relu(out, M, c0)
+            self.y = out
+            return out
+        L.pointwise_smallk(rows, w0, None, bias, out, M, Cc, c0, False)
+        a, self.bns = bn_train_forward(out, self.bn, M, c0, relu=True)
+        return a
+
+    def backward(self, d, sink) -> None:
+        M, Cc, c0 = self.M, self.Cc, self.c0
+        if self.bn is None:
+            n4 = (M * c0 + 3) // 4 * 4
+            _ck(_lib().bevf_relu_mask_f32(d.data_ptr(), self.y.data_ptr(), n4, _st()), "bevf_relu_mask_f32")
+            draw = d
+        else:
+            draw, dgamma, dbeta = bn_train_backward(d, self.bns, self.bn, relu=True)
+            sink.add(self.bn.weight, dgamma)
+            sink.add(self.bn.bias, dbeta)
+        if self.conv.bias is not None:
+            sink.add(self.conv.bias, colsum(draw, M, c0))
+        dw = _zeros(c0 * Cc, d.device)
+        _ck(_lib().bevf_smallk_wgrad_f32(draw.data_ptr(), self.rows.data_ptr(), dw.data_ptr(), M, Cc, c0, _st()),
+            "bevf_smallk_wgrad_f32")
+        sink.add(self.conv.weight, dw[:c0 * Cc])
+
+
 LOWRANK_GMAX_BACKWARD = True  # PointNet's last layer (conv -> BatchNorm -> ReLU -> max over points): weight / data gradients through
                               # a K x K Gram matrix instead of the dense M x C gradient (half the GEMM FLOPs, no 1.15 GB tensor)
 FUSE_POOL_BN_BACKWARD = True  # stem: BatchNorm + ReLU evaluated inside the max-pool (forward) and the max-pool backward gathered inside
@@ -785,45 +847,35 @@ class DetectorTape:
         rows = enc._rows(pts)
         B, Np, Cc = rows.shape
         M = B * Np
-        dev = rows.device
-        self.pts_rows, self.pn_geom = rows, (B, Np, Cc)
-        w0 = enc.conv1.weight.detach().reshape(enc.conv1.weight.shape[0], Cc).contiguous()
-        c0 = w0.shape[0]
-        raw = _new(M * c0, dev)
-        L.pointwise_smallk(rows, w0, None, enc.conv1.bias.detach(), raw, M, Cc, c0, False)
-        if not isinstance(enc.bn1, nn.BatchNorm1d):
-            raise L.BevfError("training: PointNetLiDAREncoder(use_bn=False) has no train-mode path on the device (the "
-                              "reference's config and default use BatchNorm, ref src/encoders.py:208-269); build it with "
-                              "use_bn=True")
-        a, self.pn_bn0 = bn_train_forward(raw, enc.bn1, M, c0, relu=True)
+        self.pn_geom = (B, Np, Cc)
+        self.pn_first = PointFirstLayer(enc.conv1, enc.bn1)          # bn*: BatchNorm1d, or Identity under use_bn=False
+        a = self.pn_first.forward(rows, M, Cc)
         self.pn_layers = []
         for i in range(2, 5):
-            lyr = ConvBNLayer(getattr(enc, f"conv{i}"), getattr(enc, f"bn{i}"), True)
+            lyr = ConvBNLayer(getattr(enc, f"conv{i}"), _bn_or_none(getattr(enc, f"bn{i}")), True)
             a, _, _ = lyr.forward(a, M, 1, 1)
             self.pn_layers.append(lyr)
-        lyr = ConvBNLayer(enc.conv5, enc.bn5, True)               # last layer: BN + ReLU + max over points, fused
-        g, self.pn_idx = lyr.forward_groupmax(a, B, Np)
+        lyr = ConvBNLayer(enc.conv5, _bn_or_none(enc.bn5), True)
         self.pn_layers.append(lyr)
+        if lyr.bn is not None:                                       # last layer: BN + ReLU + max over points, fused
+            g, self.pn_idx = lyr.forward_groupmax(a, B, Np)
+        else:                                                        # use_bn=False: the activation is written, then max + argmax
+            a, _, _ = lyr.forward(a, M, 1, 1)
+            g, self.pn_idx = group_max_with_index(a, B, Np, lyr.cout)
         self.pn_g = g
         return g
 
     def _lidar_backward(self, dg, sink):
-        enc = self.m.lidar_encoder
         B, Np, Cc = self.pn_geom
-        M = B * Np
-        feat = self.pn_layers[-1].cout
-        d = self.pn_layers[-1].backward_from_groupmax(dg.contiguous(), self.pn_g, self.pn_idx, B, Np, sink)
+        last = self.pn_layers[-1]
+        if last.bn is not None:
+            d = last.backward_from_groupmax(dg.contiguous(), self.pn_g, self.pn_idx, B, Np, sink)
+        else:
+            d = group_max_scatter(dg.contiguous(), self.pn_idx, B, Np, last.cout)
+            d, _ = last.backward(d, sink)
         for lyr in reversed(self.pn_layers[:-1]):
             d, _ = lyr.backward(d, sink)
-        draw, dgamma, dbeta = bn_train_backward(d, self.pn_bn0, enc.bn1, relu=True)
-        sink.add(enc.bn1.weight, dgamma)
-        sink.add(enc.bn1.bias, dbeta)
-        c0 = enc.conv1.weight.shape[0]
-        sink.add(enc.conv1.bias, colsum(draw, M, c0))
-        dw = _zeros(c0 * Cc, dg.device)
-        _ck(_lib().bevf_smallk_wgrad_f32(draw.data_ptr(), self.pts_rows.data_ptr(), dw.data_ptr(), M, Cc, c0, _st()),
-            "bevf_smallk_wgrad_f32")
-        sink.add(enc.conv1.weight, dw[:c0 * Cc])
+        self.pn_first.backward(d, sink)
 
     # -- radar: shared per-sweep MLP + max, concat -> Linear (ref src/encoders.py:628-661) --------------------------------------
     def _radar_forward(self, radars):
@@ -837,24 +889,17 @@ class DetectorTape:
             rows = enc._rows(pts)
             B, Np, Cc = rows.shape
             M = B * Np
-            w0 = enc.conv1.weight.detach().reshape(enc.conv1.weight.shape[0], Cc).contiguous()
-            c0 = w0.shape[0]
-            raw = _new(M * c0, rows.device)
-            L.pointwise_smallk(rows, w0, None, enc.conv1.bias.detach(), raw, M, Cc, c0, False)
-            a, bn0 = bn_train_forward(raw, enc.bn1, M, c0, relu=True)
+            first = PointFirstLayer(enc.conv1, enc.bn1)               # bn*: BatchNorm1d, or Identity under use_bn=False
+            a = first.forward(rows, M, Cc)
             layers = []
             for i in range(2, 5):
-                lyr = ConvBNLayer(getattr(enc, f"conv{i}"), getattr(enc, f"bn{i}"), True)
+                lyr = ConvBNLayer(getattr(enc, f"conv{i}"), _bn_or_none(getattr(enc, f"bn{i}")), True)
                 a, _, _ = lyr.forward(a, M, 1, 1)
                 layers.append(lyr)
             feat = layers[-1].cout
-            g = _new(B * feat, rows.device)
-            idx = torch.empty(B * feat, dtype=torch.int32, device=rows.device)
-            gwork = torch.empty(_lib().bevf_group_max_idx_work_bytes(B, Np, feat), dtype=torch.uint8, device=rows.device)
-            _ck(_lib().bevf_group_max_idx_f32(a.data_ptr(), g.data_ptr(), idx.data_ptr(), gwork.data_ptr(), B, Np, feat,
-                                              _st()), "bevf_group_max_idx_f32")
+            g, idx = group_max_with_index(a, B, Np, feat)
             feats.append(g[:B * feat].view(B, feat))
-            self.rad_sweeps.append((rows, bn0, layers, idx, (B, Np, Cc, c0, feat)))
+            self.rad_sweeps.append((first, layers, idx, (B, Np, feat)))
         per = torch.stack(feats, dim=1).contiguous()                      # (B, R, feat) -- layout copy only
         B, R, feat = per.shape
         self.rad_geom = (B, R, feat)
@@ -889,22 +934,12 @@ class DetectorTape:
         else:
             dper = self.rad_fc.backward(dfeat, sink)                        # [B][R][feat]
         for r in reversed(range(R)):
-            rows, bn0, layers, idx, (B, Np, Cc, c0, feat) = self.rad_sweeps[r]
-            M = B * Np
+            first, layers, idx, (B, Np, feat) = self.rad_sweeps[r]
             dg = dper[:B * R * feat].view(B, R, feat)[:, r].contiguous().view(-1)
-            d = _zeros(M * feat, dg.device)
-            _ck(_lib().bevf_group_max_bwd_f32(dg.data_ptr(), idx.data_ptr(), d.data_ptr(), B, Np, feat, _st()),
-                "bevf_group_max_bwd_f32")
+            d = group_max_scatter(dg, idx, B, Np, feat)
             for lyr in reversed(layers):
                 d, _ = lyr.backward(d, sink)
-            draw, dgamma, dbeta = bn_train_backward(d, bn0, enc.bn1, relu=True)
-            sink.add(enc.bn1.weight, dgamma)
-            sink.add(enc.bn1.bias, dbeta)
-            sink.add(enc.conv1.bias, colsum(draw, M, c0))
-            dw = _zeros(c0 * Cc, dg.device)
-            _ck(_lib().bevf_smallk_wgrad_f32(draw.data_ptr(), rows.data_ptr(), dw.data_ptr(), M, Cc, c0, _st()),
-                "bevf_smallk_wgrad_f32")
-            sink.add(enc.conv1.weight, dw[:c0 * Cc])
+            first.backward(d, sink)
 
     # -- fusion + head -----------------------------------------------------------------------------------------------------------
     def forward(self, imgs, pts, radars):
@@ -1193,6 +1228,13 @@ def any_bn_training(module: nn.Module) -> bool:
     return any(isinstance(m, nn.modules.batchnorm._BatchNorm) and m.training for m in module.modules())
 
 
+def wants_train_path(module: nn.Module) -> bool:
+    """A module in train mode takes the tape when BatchNorm runs on batch statistics somewhere in it -- or when it has no BatchNorm at
+    all (use_bn=False encoders, ref src/encoders.py:258-269, 520-529) and autograd is recording: the eval engines keep no gradient path."""
+    has_bn = any(isinstance(m, nn.modules.batchnorm._BatchNorm) for m in module.modules())
+    return any_bn_training(module) if has_bn else torch.is_grad_enabled()
+
+
 def _require_all_bn_training(model: nn.Module) -> None:
     for name, mod in model.named_modules():
         if isinstance(mod, nn.modules.batchnorm._BatchNorm) and not mod.training:
@@ -1296,6 +1338,32 @@ def pointnet_train_forward(enc, x: torch.Tensor) -> torch.Tensor:
         return [None]
 
     (out,) = _ModuleTrainFn.apply(fwd, bwd, 1, x, *[p for p in enc.parameters() if p.requires_grad])
+    return out
+
+
+def vfe_train_forward(layer, x: torch.Tensor) -> torch.Tensor:
+    """VFELayer.forward under train-mode BatchNorm (ref src/encoders.py:431-455): Linear -> BatchNorm1d over all B*Nv*P rows (padding
+    rows included, as the reference) -> ReLU -> max over the P points of a voxel -> (B, Nv, out_channels)."""
+    _require_all_bn_training(layer)
+    _no_input_grad(x, "the voxel points")
+    B, Nv, P, Cc = x.shape                                        # a 3-D input raises ValueError exactly like the reference
+    if Cc > 16:
+        raise L.BevfError(f"training: VFELayer(in_channels={Cc}) has a train-mode path for point features of <= 16 channels only")
+    G, M = B * Nv, B * Nv * P
+    lin = SimpleNamespace(weight=layer.linear.weight, bias=layer.linear.bias)      # same Parameters: gradients land on them
+
+    def fwd():
+        first = PointFirstLayer(lin, layer.bn)
+        a = first.forward(x.detach().float().contiguous().view(M, Cc), M, Cc)
+        g, idx = group_max_with_index(a, G, P, first.c0)
+        return (first, idx), (g[:G * first.c0].view(B, Nv, first.c0),)
+
+    def bwd(tape, douts, sink):
+        first, idx = tape
+        first.backward(group_max_scatter(douts[0].contiguous().float().reshape(-1), idx, G, P, first.c0), sink)
+        return [None]
+
+    (out,) = _ModuleTrainFn.apply(fwd, bwd, 1, x, *[p for p in layer.parameters() if p.requires_grad])
     return out
 
 

@@ -302,11 +302,12 @@ def test_lidar_resize_extension_128(gpu):
 
 
 def test_modules_without_a_train_mode_path_refuse_it(gpu):
-    """Train-mode BatchNorm runs through training.DetectorTape for the detector and its five module kinds
-    (tests/test_gpu_standalone_train.py); VFELayer has no tape, and mixed-mode BatchNorm is not built: both refuse loudly."""
-    v = encoders.VFELayer(4, 32).cuda().train()
-    with pytest.raises(RuntimeError, match="call .eval\\(\\) first"):
-        v(torch.zeros(1, 3, 5, 4, device=gpu))
+    """Train-mode BatchNorm runs through training.DetectorTape for the detector and its module kinds
+    (tests/test_gpu_standalone_train.py); mixed-mode BatchNorm is not built and refuses loudly, and so does a VFELayer wider than
+    the small-K point kernel."""
+    v = encoders.VFELayer(32, 32).cuda().train()
+    with pytest.raises(RuntimeError, match="<= 16 channels"):
+        v(torch.zeros(1, 3, 5, 32, device=gpu))
     m = encoders.ResNetCameraEncoder(backbone="resnet18", pretrained=False).cuda().train()
     m.layer2[0].bn1.eval()
     with pytest.raises(RuntimeError, match="mixed-mode BatchNorm"):
