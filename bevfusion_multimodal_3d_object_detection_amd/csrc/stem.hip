@@ -878,7 +878,14 @@ __global__ __launch_bounds__(256) void stem_pool7x7_bf16mma(const float* __restr
 // bit-identical to stem_pool7x7_bf16mma for finite images (the kw = 7 product is pixel x 0 instead of 0 x 0).
 constexpr int RPB = PW * 2;                                        // bytes per patch row of one copy (264 bf16)
 constexpr int COPYB = ((3 * PR * RPB + 255) / 256) * 256 + 128;    // copy stride: == 128 (mod 256)
-constexpr size_t kStemBf16V2Lds = (size_t)2 * COPYB;
+// The pooled row leaves through a per-wave LDS transpose: a lane holds ONE channel of 8 pooled pixels (2-byte stores, 8 per lane and
+// half row: in-kernel ablation put 40 % of the kernel on them); written as bf16 to [16 pixels][32 channels] and read back as 16-byte
+// pieces, a wave stores its 16 x 64 bytes with ONE b128 store per lane.  Wave-local: no barrier.
+constexpr int TPITCH = 80;                                         // bytes per pixel of a transpose tile (64 + 16: the two lane halves hit different banks)
+constexpr int TTILE = 16 * TPITCH;                                 // one (wave, half row) tile
+constexpr size_t kStemBf16V2Lds = (size_t)2 * COPYB + (size_t)4 * 2 * TTILE;
+constexpr int QPR = PW / 4;                                        // 16-byte quads per patch row (66)
+constexpr int NITEM = 3 * PR * QPR, NIT = (NITEM + 255) / 256;     // staging items (row, quad) per chunk: 2574 = 10 x 256 + 14
 __host__ __device__ constexpr int stem_row_of(int r) { return r >= 21 ? (2 * PR + 6) : (r / 7) * PR + (r % 7); }   // k-group -> patch row (group 21: zero filter)
 
 __global__ __launch_bounds__(256) void stem_pool7x7_bf16v2(const float* __restrict__ x, const __bf16* __restrict__ w,
@@ -922,7 +929,8 @@ __global__ __launch_bounds__(256) void stem_pool7x7_bf16v2(const float* __restri
   }
   const int hrow1 = h * RPB, hrow7 = h * (PR - 6) * RPB;
   const bool all_cols = ow0 >= 0 && ow0 + 3 * WPX + 32 <= Wo;      // every stem column the four wave tiles touch exists
-  const bool vec_ok = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
+  const bool vec_ok = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) && (long long)3 * H * W * 4 < (1ll << 31);
+  const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)n * 3 * H * W), 0, 3 * H * W * 4, 0x00020000);
   float prev1[2][8], prev2[2][8];                                  // [half][centre]: horizontal maxima of the last two stem rows
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -931,30 +939,56 @@ __global__ __launch_bounds__(256) void stem_pool7x7_bf16v2(const float* __restri
 
   for (int oh0 = r_first; oh0 <= r_last; oh0 += TH) {
     __syncthreads();                                               // the previous chunk's patch (or the filter bank) is consumed
-    {                                                              // patch rows 2*oh0 - 3 .., columns 2*ow0 - 4 .. -> the two shifted bf16 copies
-      const float* img = x + (size_t)n * 3 * H * W;
-      const int iw0 = 2 * ow0 - 4;
+    const float* img = x + (size_t)n * 3 * H * W;
+    const int iw0 = 2 * ow0 - 4;
+    if (vec_ok) {
+      // patch rows 2*oh0 - 3 .., columns 2*ow0 - 4 .. -> the two shifted bf16 copies.  ALL loads of the chunk first (a thread owns up to
+      // NIT (row, quad) items; 2 x 16 bytes each: columns 4 c4 .. + 7, the second load is the neighbour's first -- a cache hit), ONE
+      // wait, then the conversions: the per-row loop this replaces paid a memory latency per row (in-kernel ablation: 53 % of the kernel)
+      f32x4 sv[NIT], su[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int i = it * 256 + tid;
+        const int r = (i * 993) >> 16, c4 = i - r * QPR;              // i / 66 for i < 2816
+        const int c = (r * 5042) >> 16, pr = r - c * PR;              // r / 13 for r < 42
+        const int ih = 2 * oh0 - 3 + pr, iw = iw0 + 4 * c4;
+        // (one unsigned compare per bound, folded into the offset at once: no lane masks kept across the loads)
+        unsigned ro = (unsigned)(((c * H + ih) * W + iw) * 4);
+        ro = ((it < NIT - 1 || i < NITEM) && (unsigned)ih < (unsigned)H) ? ro : 0x80000000u;
+        sv[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rimg, (unsigned)iw < (unsigned)W ? ro : 0x80000000u, 0, 0));
+        su[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rimg, (unsigned)(iw + 4) < (unsigned)W ? ro + 16u : 0x80000000u, 0, 0));
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int i = it * 256 + tid;
+        const int r = (i * 993) >> 16, c4 = i - r * QPR;
+        const f32x4 v = sv[it], u = su[it];
+        // copy 0 holds patch column e + 1 at element e, copy 1 column e + 3: elements 4 c4 .. 4 c4 + 3 of both
+        bf16x4s a0, a1;
+        a0[0] = (__bf16)v[1]; a0[1] = (__bf16)v[2]; a0[2] = (__bf16)v[3]; a0[3] = (__bf16)u[0];
+        a1[0] = a0[2]; a1[1] = a0[3]; a1[2] = (__bf16)u[1]; a1[3] = (__bf16)u[2];
+        if (it < NIT - 1 || i < NITEM) {
+          *reinterpret_cast<bf16x4s*>(lds + (size_t)r * RPB + 8 * c4) = a0;
+          *reinterpret_cast<bf16x4s*>(lds + COPYB + (size_t)r * RPB + 8 * c4) = a1;
+        }
+      }
+    } else {                                                       // unaligned image / odd width: the scalar path, row by row
       const int wv = __builtin_amdgcn_readfirstlane(wave);
       for (int r = wv; r < 3 * PR; r += 4) {
         const int c = r / PR, pr = r - c * PR;
         const int ih = 2 * oh0 - 3 + pr;
         const bool row_ok = (unsigned)ih < (unsigned)H;
         const float* row = img + ((size_t)c * H + (row_ok ? ih : 0)) * W;
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(row), 0, row_ok ? W * 4 : 0, 0x00020000);
-        for (int c4 = lane; c4 < PW / 4; c4 += 64) {
+        for (int c4 = lane; c4 < QPR; c4 += 64) {
           const int iw = iw0 + 4 * c4;
           f32x4 v = {0.f, 0.f, 0.f, 0.f}, u = {0.f, 0.f, 0.f, 0.f};    // patch columns 4 c4 .. + 3 and the next four
-          if (vec_ok) {
-            v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, iw >= 0 ? (unsigned)(iw * 4) : 0x80000000u, 0, 0));
-            u = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, iw + 4 >= 0 ? (unsigned)((iw + 4) * 4) : 0x80000000u, 0, 0));
-          } else if (row_ok) {
+          if (row_ok) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               if ((unsigned)(iw + j) < (unsigned)W) v[j] = row[iw + j];
               if ((unsigned)(iw + 4 + j) < (unsigned)W) u[j] = row[iw + 4 + j];
             }
           }
-          // copy 0 holds patch column e + 1 at element e, copy 1 column e + 3: elements 4 c4 .. 4 c4 + 3 of both
           bf16x4s a0, a1;
           a0[0] = (__bf16)v[1]; a0[1] = (__bf16)v[2]; a0[2] = (__bf16)v[3]; a0[3] = (__bf16)u[0];
           a1[0] = a0[2]; a1[1] = a0[3]; a1[2] = (__bf16)u[1]; a1[3] = (__bf16)u[2];
@@ -1018,14 +1052,20 @@ __global__ __launch_bounds__(256) void stem_pool7x7_bf16v2(const float* __restri
         if (oh & 1) {                                              // stem row 2p+1 completes pooled row p (uniform branch)
           const int pr = (oh - 1) >> 1;
           if (pr >= p0 && pr < p1) {
-            __bf16* const yrow = y + ((size_t)(n * Hp + pr) * Wp) * 64 + ni * 32 + l31;
+            // this wave's 16 pooled pixels x 32 channels through its transpose tile (see TPITCH): lane (l31, h) holds channel l31 of
+            // pixels 4 (c >> 1) + (c & 1) + 2 h; lane (pixel = lane >> 2, piece = lane & 3) then stores 8 channels of one pixel
+            char* const tt = lds + 2 * COPYB + (wave * 2 + hf) * TTILE;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-              const int rc = 2 * c;
-              const int cc = col0 + (rc & 3) + 8 * (rc >> 2);      // stem column of the window centre (even)
-              const bool own = (h != 0 || c != 0) && cc >= 0 && (cc >> 1) < Wp;
-              if (own) yrow[(size_t)(cc >> 1) * 64] = (__bf16)fmaxf(fmaxf(prev2[hf][c], prev1[hf][c]), hm[c]);
-            }
+            for (int c = 0; c < 8; ++c)
+              *reinterpret_cast<__bf16*>(tt + (4 * (c >> 1) + (c & 1) + 2 * h) * TPITCH + 2 * l31) =
+                  (__bf16)fmaxf(fmaxf(prev2[hf][c], prev1[hf][c]), hm[c]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int px = lane >> 2, piece = lane & 3;
+            const u32x4 q = *reinterpret_cast<const u32x4*>(tt + px * TPITCH + piece * 16);
+            const int cc = ow0 + hf * 2 * WPX + mi * WPX + 2 * px;      // stem column of the window centre (even); pixel 0 is the left neighbour's
+            if (px != 0 && cc >= 0 && (cc >> 1) < Wp)
+              *reinterpret_cast<u32x4*>(y + ((size_t)(n * Hp + pr) * Wp + (cc >> 1)) * 64 + ni * 32 + piece * 8) = q;
+            asm volatile("" ::: "memory");
           }
         }
 #pragma unroll

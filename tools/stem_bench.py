@@ -31,3 +31,6 @@ wp = L.stem_pack_bf16(w[:147].t().reshape(64, 3, 7, 7).contiguous())
 yb = torch.empty(N * Ho * Wo * 64, dtype=torch.bfloat16, device=dev)
 ms = t(lambda: L.stem_conv7x7_bf16mma(x, wp, sc, sh, yb, N, H, W, relu=True))
 print(f"stem bf16-MFMA {ms*1e3:8.1f} us  {fl/ms/1e9:6.1f} TF   (read {x.numel()*4/ms/1e6:.0f} + write {yb.numel()*2/ms/1e6:.0f} GB/s)")
+pb = torch.empty(N * Hp * Wp * 64, dtype=torch.bfloat16, device=dev)
+ms = t(lambda: L.stem_pool_bf16mma(x, wp, sc, sh, pb, N, H, W))
+print(f"stem+pool bf16 {ms*1e3:8.1f} us  {fl/ms/1e9:6.1f} TF   (read {x.numel()*4/ms/1e6:.0f} + write {pb.numel()*2/ms/1e6:.0f} GB/s)")
