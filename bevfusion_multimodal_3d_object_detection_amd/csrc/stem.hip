@@ -57,19 +57,29 @@ __device__ __forceinline__ void stage_patch(const float* __restrict__ x, float* 
     const unsigned va = (unsigned)iwa < (unsigned)W ? (unsigned)(iwa * 4) : 0x80000000u;
     const unsigned vb = (lane < 2 && (unsigned)iwb < (unsigned)W) ? (unsigned)(iwb * 4) : 0x80000000u;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
-    for (int r = wv; r < 3 * PR; r += 4) {
+    // ALL of the wave's rows are requested before the first one is written (the row-by-row loop paid one memory latency per row);
+    // a row outside the image is a zero-length buffer: its loads return zeros, no branch
+    constexpr int NR = (3 * PR + 3) / 4;
+    u32x4 v0[NR], v1[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int r = wv + 4 * k;
       const int c = r / PR, pr = r - c * PR;
       const int ih = 2 * oh0 - 3 + pr;
-      char* const dst = reinterpret_cast<char*>(patch) + r * (PW * 4) + lane * 16;
-      u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
-      if ((unsigned)ih < (unsigned)H) {             // wave-uniform
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(img) + ((size_t)c * H + ih) * W, 0, W * 4, 0x00020000);
-        v0 = __builtin_amdgcn_raw_buffer_load_b128(rx, va, 0, 0);
-        v1 = __builtin_amdgcn_raw_buffer_load_b128(rx, vb, 0, 0);
+      const bool ok = r < 3 * PR && (unsigned)ih < (unsigned)H;      // wave-uniform
+      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(img) + (ok ? ((size_t)c * H + ih) * W : 0), 0, ok ? W * 4 : 0, 0x00020000);
+      v0[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, va, 0, 0);
+      v1[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, vb, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int r = wv + 4 * k;
+      if (r < 3 * PR) {
+        char* const dst = reinterpret_cast<char*>(patch) + r * (PW * 4) + lane * 16;
+        *reinterpret_cast<u32x4*>(dst) = v0[k];
+        if (lane < 2) *reinterpret_cast<u32x4*>(dst + 1024) = v1[k];
       }
-      *reinterpret_cast<u32x4*>(dst) = v0;
-      if (lane < 2) *reinterpret_cast<u32x4*>(dst + 1024) = v1;
     }
   } else {
 #pragma unroll 8

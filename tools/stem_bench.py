@@ -27,6 +27,8 @@ fl = 2.0 * N * Ho * Wo * 64 * 147
 print(f"stem   {ms*1e3:8.1f} us  {fl/ms/1e9:6.1f} TF   (write {y.numel()*4/ms/1e6:.0f} GB/s)")
 ms = t(lambda: L.maxpool3x3s2(y, p, N, Ho, Wo, 64))
 print(f"maxpool{ms*1e3:8.1f} us  algorithmic {(y.numel()+p.numel())*4/ms/1e6:.0f} GB/s")
+ms = t(lambda: L.stem_pool(x, w.view(-1), sc, sh, p, N, H, W))
+print(f"stem+pool fp32 {ms*1e3:8.1f} us  {fl/ms/1e9:6.1f} TF")
 wp = L.stem_pack_bf16(w[:147].t().reshape(64, 3, 7, 7).contiguous())
 yb = torch.empty(N * Ho * Wo * 64, dtype=torch.bfloat16, device=dev)
 ms = t(lambda: L.stem_conv7x7_bf16mma(x, wp, sc, sh, yb, N, H, W, relu=True))
