@@ -56,7 +56,8 @@ static void fastdiv_make(int d, unsigned* mul, unsigned* sh) {
 // j = lane&31 (channel) and i = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel).  T = storage type of y / res.
 template <typename T, int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[WM / 32][WN / 32], const int m0,
-                                              const int n0, const int m_hi, const int wm, const int wn, const int lane) {
+                                              const int n0, const int m_hi, const int wm, const int wn, const int lane,
+                                              char* const scratch = nullptr) {
   constexpr int ES = (int)sizeof(T);
   constexpr bool kF32 = std::is_same<T, float>::value;
   constexpr int MI = WM / 32, NI = WN / 32;
@@ -110,6 +111,44 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[W
     };
     using TT = std::true_type;
     using FF = std::false_type;
+    if constexpr (!kF32) {
+      // bf16 output without a residual: the accumulator layout puts ONE channel of 16 pixels in a lane -- 2-byte stores, 16 per 32x32
+      // tile, 64-byte runs (the access SHAPE that bounded conv3x3_bf16's short-K layers and 40 % of the bf16 stem).  Through a wave-local
+      // LDS transpose (scratch: the operand tiles are dead after the K loop's last barrier) a lane stores 16 bytes = 8 channels of a pixel
+      // and a wave row is WN * 2 contiguous bytes (a whole 128-byte line at WN = 64).  Same values, same rounding.
+      if (scratch && !p.res && (p.y_cs * ES) % 16 == 0 && (reinterpret_cast<uintptr_t>(p.y) & 15u) == 0) {
+        constexpr int PITCH = NI * 64 + 16;                           // bytes per pixel row of the wave's tile (pad: the two lane halves on different banks)
+        constexpr int PPP = NI * 4;                                   // 16-byte pieces per pixel
+        char* const ws = scratch + (wm * (BN / WN) + wn) * (32 * PITCH);
+        float scv[NI], shv[NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          scv[ni] = p.scale ? p.scale[n_base + ni * 32 + l31] : 1.f;
+          shv[ni] = p.shift ? p.shift[n_base + ni * 32 + l31] : 0.f;
+        }
+        const bool relu = p.relu != 0;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float t = fmaf(acc[mi][ni][r], scv[ni], shv[ni]);
+              t = relu ? fmaxf(t, 0.f) : t;
+              *reinterpret_cast<__bf16*>(ws + ((r & 3) + 8 * (r >> 2) + 4 * h) * PITCH + (ni * 32 + l31) * 2) = (__bf16)t;
+            }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int k = 0; k < NI * 2; ++k) {
+            const int idx = k * 64 + lane, px = idx / PPP, piece = idx - px * PPP;
+            const u32x4 q = *reinterpret_cast<const u32x4*>(ws + px * PITCH + piece * 16);
+            __builtin_amdgcn_raw_buffer_store_b128(q, ry, (unsigned)(((mi * 32 + px) * p.y_cs) * ES + piece * 16), 0, 0);
+          }
+          asm volatile("" ::: "memory");
+        }
+        return;
+      }
+    }
     if (p.res) { if (p.relu) run(TT{}, TT{}); else run(TT{}, FF{}); }
     else       { if (p.relu) run(FF{}, TT{}); else run(FF{}, FF{}); }
     return;

@@ -242,7 +242,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, float* lds, const i
     __syncthreads();
   }
 
-  conv_epilogue<T, BM, BN, WM, WN>(p, acc, m0, n0, m_hi, wm, wn, lane);
+  conv_epilogue<T, BM, BN, WM, WN>(p, acc, m0, n0, m_hi, wm, wn, lane, reinterpret_cast<char*>(lds));
 }
 
 // single tile shape over all rows

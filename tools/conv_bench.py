@@ -29,6 +29,8 @@ SHAPES = {  # name: (N, H, W, Cin, Cout, k, stride, pad)
     "l3s2_b8": (48, 113, 200, 128, 256, 3, 2, 1),
     "proj_b8": (48, 57, 100, 256, 512, 1, 1, 0),
     "layer3_b1": (6, 57, 100, 256, 256, 3, 1, 1),
+    "ds2_b8": (48, 225, 400, 64, 128, 1, 2, 0),              # the 1x1 / stride 2 downsample convolutions
+    "ds3_b8": (48, 113, 200, 128, 256, 1, 2, 0),
 }
 dev = torch.device("cuda")
 names = sys.argv[1].split(",") if len(sys.argv) > 1 else list(SHAPES)
