@@ -12,3 +12,8 @@ echo "stamps done"
     BEVF_AB_LIB=build/old/libbevf_oldvox.so timeout -k 10 200 python tools/frontend_bench.py 3
   fi; } > gpurun_out/r03_frontend_bench.txt 2>&1
 echo "frontend done"
+{ timeout -k 10 200 python tools/wino_bench.py
+  for l in layer1 layer1r layer2 layer3 fusion1; do timeout -k 10 100 python tools/wino_stamps.py $l 0; done; } > gpurun_out/r03_wino_bench.txt 2>&1
+echo "wino done"
+timeout -k 10 200 python tools/stem_bench.py 48 > gpurun_out/r03_stem_bench.txt 2>&1
+echo "stem done"

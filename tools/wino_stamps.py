@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Where a wino_f32 workgroup spends its life: in-kernel s_memtime stamps of a diagnostic launch (start / first operands transformed /
-K loop done / epilogue issued / stores acknowledged), per workgroup; medians in s_memtime ticks (100 MHz: 10 ns) and shares.
+K loop done / epilogue issued / stores acknowledged), per workgroup; p10 / p50 / p90 in s_memtime ticks and shares.  The last line gives the
+tick rate: one workgroup per CU is resident, so sum of lives / (256 CUs x launch time) = ticks per second (it comes out at ~2.0-2.4 GHz:
+the ticks are shader cycles).
 usage: wino_stamps.py [layer] [tile]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -38,5 +40,5 @@ print(f"{name} tile={tile}: {t.shape[0]} workgroups, launch {e0.elapsed_time(e1)
 for i, lab in enumerate(("prologue (first DMA, wait, first input transform)", "K loop", "epilogue issue (transform, residual, stores)",
                          "store acknowledgement")):
     print(f"  {lab:50s} p10/p50/p90 ticks {q(d[:, i])}  share of life {float(d[:, i].sum() / life.sum()):.3f}")
-print(f"  workgroup life p10/p50/p90 {q(life)} ticks of 10 ns; sum of lives / (256 CUs x launch) = "
-      f"{float(life.sum()) * 10e-9 / (256 * e0.elapsed_time(e1) * 1e-3):.3f}")
+print(f"  workgroup life p10/p50/p90 {q(life)} ticks; sum of lives / (256 CUs x launch) = "
+      f"{float(life.sum()) / (256 * e0.elapsed_time(e1) * 1e-3) / 1e9:.2f} G ticks/s")
