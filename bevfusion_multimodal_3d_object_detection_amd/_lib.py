@@ -177,6 +177,8 @@ SIGNATURES = {
     "bevf_group_max_idx_work_bytes": (C.c_size_t, [C.c_int] * 3),
     "bevf_group_max_idx_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
     "bevf_group_max_bwd_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
+    "bevf_sparse_rows_wgrad_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
+    "bevf_sparse_rows_scatter_add_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
     "bevf_linear_bwd_work_floats": (C.c_size_t, [C.c_int] * 3),
     "bevf_linear_bwd_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_void_p]),
     "bevf_head_tail_bwd_f32": (C.c_int, [C.POINTER(HeadBwdDesc), C.c_void_p]),

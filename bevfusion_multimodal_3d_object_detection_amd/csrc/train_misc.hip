@@ -247,6 +247,39 @@ __global__ __launch_bounds__(256) void group_max_bwd(const float* __restrict__ d
   }
 }
 
+// ---- the sparse rows of the low-rank group-max backward (training._backward_from_groupmax_lowrank): S [G][C] holds one entry per (group,
+// channel), sitting at row g*P + idx[g][c] of the [G*P][K] activation.  Both kernels add in a FIXED order (no atomics): run-to-run bit-identical.
+// sparse_rows_wgrad: out[c][k] = sum_g S[g][c] * A[g*P + idx[g][c]][k]                       (groups in ascending order)
+__global__ __launch_bounds__(256) void sparse_rows_wgrad(const float* __restrict__ S, const int* __restrict__ idx,
+                                                          const float* __restrict__ A, float* __restrict__ out, int G, int P, int C,
+                                                          int K) {
+  const int c = blockIdx.x;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    float acc = 0.f;
+    for (int g = 0; g < G; ++g) acc = fmaf(S[(size_t)g * C + c], A[((size_t)g * P + idx[(size_t)g * C + c]) * K + k], acc);
+    out[(size_t)c * K + k] = acc;
+  }
+}
+// sparse_rows_scatter: dA[g*P + idx[g][c]][k] += sum over the channels c' of group g that share that row (ascending c') of S[g][c'] * W[c'][k].
+// One workgroup per (g, c): the FIRST channel of a row owns it and walks the later ones; the others leave.  Rows of different owners differ.
+__global__ __launch_bounds__(256) void sparse_rows_scatter(const float* __restrict__ S, const int* __restrict__ idx,
+                                                            const float* __restrict__ Wt, float* __restrict__ dA, int P, int C, int K) {
+  extern __shared__ int srow[];                                    // idx[g][0..C)
+  const int g = blockIdx.y, c = blockIdx.x;
+  for (int i = threadIdx.x; i < C; i += 256) srow[i] = idx[(size_t)g * C + i];
+  __syncthreads();
+  const int row = srow[c];
+  for (int j = 0; j < c; ++j)
+    if (srow[j] == row) return;                                    // (uniform: every thread reads the same LDS words)
+  float* const dst = dA + ((size_t)g * P + row) * K;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    float acc = 0.f;
+    for (int j = c; j < C; ++j)
+      if (srow[j] == row) acc = fmaf(S[(size_t)g * C + j], Wt[(size_t)j * K + k], acc);
+    dst[k] += acc;
+  }
+}
+
 // ---- zero stuffing for the data gradient of strided convs: out[n][s*oh][s*ow][c] = dy[n][oh][ow][c], 0 elsewhere -----
 __global__ __launch_bounds__(256) void zero_stuff(const float* __restrict__ dy, float* __restrict__ out, int N, int Ho,
                                                    int Wo, int C, int H, int W, int s) {
@@ -714,6 +747,18 @@ extern "C" int bevf_group_max_bwd_f32(const float* dy, const int32_t* idx, float
   const long long total = (long long)G * C;
   hipLaunchKernelGGL(group_max_bwd, dim3(ew_grid(total)), dim3(256), 0, ST, dy, idx, dx, P, C, total);
   return bevf_check_launch("bevf_group_max_bwd_f32");
+}
+extern "C" int bevf_sparse_rows_wgrad_f32(const float* S, const int32_t* idx, const float* A, float* out, int G, int P, int C, int K,
+                                          void* stream) {
+  BEVF_REQUIRE(S && idx && A && out && G > 0 && P > 0 && C > 0 && K > 0, "sparse_rows_wgrad: bad arguments");
+  hipLaunchKernelGGL(sparse_rows_wgrad, dim3((unsigned)C), dim3(256), 0, ST, S, idx, A, out, G, P, C, K);
+  return bevf_check_launch("bevf_sparse_rows_wgrad_f32");
+}
+extern "C" int bevf_sparse_rows_scatter_add_f32(const float* S, const int32_t* idx, const float* W, float* dA, int G, int P, int C, int K,
+                                                void* stream) {
+  BEVF_REQUIRE(S && idx && W && dA && G > 0 && G < 65536 && P > 0 && C > 0 && C <= 16384 && K > 0, "sparse_rows_scatter_add: bad arguments");
+  hipLaunchKernelGGL(sparse_rows_scatter, dim3((unsigned)C, (unsigned)G), dim3(256), (size_t)C * sizeof(int), ST, S, idx, W, dA, P, C, K);
+  return bevf_check_launch("bevf_sparse_rows_scatter_add_f32");
 }
 extern "C" int bevf_zero_stuff_nhwc_f32(const float* dy, float* out, int N, int Ho, int Wo, int C, int H, int W, int s,
                                         void* stream) {

@@ -644,23 +644,26 @@ class ConvBNLayer:
         kap = -(gi * invstd) * dgamma / M
         bias = self.conv.bias.detach() if self.conv.bias is not None else torch.zeros(Cc, device=dev)
         beta_p = -(gi * dbeta) / M + kap * (bias - mean)
-        S = gi.unsqueeze(0) * dgm[:B * Cc].view(B, Cc)                                     # [B][C]
-        rows = (torch.arange(B, device=dev).unsqueeze(1) * P + idx[:B * Cc].view(B, Cc).long())      # argmax rows [B][C]
-        A = self.x[:M * K].view(M, K)
+        S = (gi.unsqueeze(0) * dgm[:B * Cc].view(B, Cc)).contiguous()                      # [B][C] (parameter-sized torch arithmetic)
         cs_a = colsum(self.x, M, K)                                                       # 1^T A
         if self.conv.bias is not None:
             sink.add(self.conv.bias, S.sum(0) + M * beta_p + kap * (W2 * cs_a.unsqueeze(0)).sum(1))
         # weight gradient: K x K Gram matrix on the pixel-GEMM kernel, the rest is C x K sized
         gram = conv_wgrad(self.x, self.x, M, 1, 1, K, K, 1, 1, 0).reshape(K, K)
         wg, _, _ = conv_raw(W2.contiguous().view(-1), gram.contiguous().view(-1), None, Cc, 1, 1, K, K, 1, 1, 0)
-        dW = (S.unsqueeze(2) * A[rows]).sum(0) + beta_p.unsqueeze(1) * cs_a.unsqueeze(0) + kap.unsqueeze(1) * wg[:Cc * K].view(Cc, K)
+        sa = _new(Cc * K, dev)                                                            # S^T A over the B*C argmax rows, frames in order
+        _ck(_lib().bevf_sparse_rows_wgrad_f32(S.data_ptr(), idx.data_ptr(), self.x.data_ptr(), sa.data_ptr(), B, P, Cc, K, _st()),
+            "bevf_sparse_rows_wgrad_f32")
+        dW = sa[:Cc * K].view(Cc, K) + beta_p.unsqueeze(1) * cs_a.unsqueeze(0) + kap.unsqueeze(1) * wg[:Cc * K].view(Cc, K)
         sink.add(w, dW.reshape(w.shape))
         # data gradient: A (W^T diag(kappa) W) + the row-constant term in ONE 1x1-conv launch, then the B*C sparse rows
         kw = (kap.unsqueeze(1) * W2).contiguous()
         gw = conv_wgrad(W2.contiguous().view(-1), kw.view(-1), Cc, 1, 1, K, K, 1, 1, 0).reshape(K, K)
         v = (beta_p.unsqueeze(1) * W2).sum(0).contiguous()
         dA, _, _ = conv_raw(self.x, gw.contiguous().view(-1), v, M, 1, 1, K, K, 1, 1, 0)
-        dA[:M * K].view(M, K).index_add_(0, rows.reshape(-1), (S.reshape(-1, 1) * W2.repeat(B, 1)))
+        # + S W at the argmax rows: channels sharing a row are added by the row's first channel, in order (no atomics: reproducible)
+        _ck(_lib().bevf_sparse_rows_scatter_add_f32(S.data_ptr(), idx.data_ptr(), W2.contiguous().data_ptr(), dA.data_ptr(), B, P, Cc, K,
+                                                    _st()), "bevf_sparse_rows_scatter_add_f32")
         return dA
 
     def _conv_backward(self, dxraw, sink: GradSink, need_dx=True, add=None, fuse_next=None):

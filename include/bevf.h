@@ -456,6 +456,11 @@ int bevf_cam_mean_bwd_f32(const float* dy, float* dx, int B, int ncam, int P, in
 size_t bevf_group_max_idx_work_bytes(int G, int P, int C);
 int bevf_group_max_idx_f32(const float* x, float* y, int32_t* idx, void* work, int G, int P, int C, void* stream);
 int bevf_group_max_bwd_f32(const float* dy, const int32_t* idx, float* dx, int G, int P, int C, void* stream); /* dx zero-filled */
+/* The sparse rows of the low-rank backward of conv -> BatchNorm -> ReLU -> max over points (ref src/encoders.py:296-299): S [G][C] = one entry
+ * per (frame, channel), living at row g*P + idx[g][c] of the [G*P][K] layer input A.  out[c][k] = sum_g S[g][c] A[row(g,c)][k];
+ * dA[row(g,c)][k] += S[g][c] W[c][k].  Fixed summation order, no atomics: bit-identical run to run. */
+int bevf_sparse_rows_wgrad_f32(const float* S, const int32_t* idx, const float* A, float* out, int G, int P, int C, int K, void* stream);
+int bevf_sparse_rows_scatter_add_f32(const float* S, const int32_t* idx, const float* W, float* dA, int G, int P, int C, int K, void* stream);
 /* Same max / argmax (work: bevf_group_max_idx_work_bytes) over relu(batchnorm(x)) evaluated on the fly from the raw
  * rows x with bn_apply's own fma: the training forward of PointNet's last layer writes no activation.            */
 int bevf_bn_relu_group_max_idx_f32(const float* x, const float* mean, const float* invstd, const float* gamma,

@@ -688,3 +688,31 @@ def test_lowrank_groupmax_backward_matches_the_dense_path_and_autograd(gpu, B, P
             continue
         assert rel_err(outs[True][k].cpu(), r) <= 2e-5, ("lowrank vs autograd", k)
         assert rel_err(outs[False][k].cpu(), r) <= 2e-5, ("dense vs autograd", k)
+
+
+def test_sparse_row_kernels_are_exact_and_reproducible(gpu):
+    """The B*C argmax-row terms of the low-rank backward (S^T A gather, S W scatter) as kernels with a fixed summation order (ADVICE r2:
+    torch's index_add_ with duplicate rows used float atomics): equal to a float64 evaluation to rounding, and bit-identical run to run
+    although many channels share a row.  (The layer's other terms still pass through the pixel-GEMM weight-gradient kernel, whose split
+    workgroups add with atomics: the layer as a whole is close, not bit-reproducible.)"""
+    G, P, C, K = 3, 50, 96, 40                                       # 96 channels over 50 rows: every row is shared
+    S = synth.normal((G, C), 201).cuda()
+    idx = (synth.uniform((G, C), 202, 0, 1) * P).long().clamp_(0, P - 1).int().cuda()
+    A = synth.normal((G * P, K), 203).cuda()
+    W = synth.normal((C, K), 204).cuda()
+    base = synth.normal((G * P, K), 205).cuda()
+    lib = L.lib()
+    outs = []
+    for _ in range(2):
+        sa = torch.empty(C, K, device=gpu)
+        assert lib.bevf_sparse_rows_wgrad_f32(S.data_ptr(), idx.data_ptr(), A.data_ptr(), sa.data_ptr(), G, P, C, K, None) == 0
+        dA = base.clone()
+        assert lib.bevf_sparse_rows_scatter_add_f32(S.data_ptr(), idx.data_ptr(), W.data_ptr(), dA.data_ptr(), G, P, C, K, None) == 0
+        torch.cuda.synchronize()
+        outs.append((sa, dA))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    rows = (torch.arange(G, device=gpu).unsqueeze(1) * P + idx.long())
+    ref_sa = (S.double().unsqueeze(2) * A.double()[rows]).sum(0)
+    ref_dA = base.double().index_add(0, rows.reshape(-1), (S.double().reshape(-1, 1) * W.double().repeat(G, 1)))
+    assert rel_err(outs[0][0].double(), ref_sa) <= 1e-6 and rel_err(outs[0][1].double(), ref_dA) <= 1e-6
+
