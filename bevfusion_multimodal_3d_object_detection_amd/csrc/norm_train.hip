@@ -298,13 +298,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dy
                                                      const float* __restrict__ gamma, const float* __restrict__ s_dy,
                                                      const float* __restrict__ s_dyx, float* __restrict__ dx,
                                                      long long M, int C, int cs, const float* __restrict__ beta = nullptr,
-                                                     int remask = 0) {
+                                                     int remask = 0, int frozen = 0) {
   const int c4 = C >> 2;
   const int lanes = c4 >= 256 ? 1 : 256 / c4;
   const int rl = c4 >= 256 ? 0 : threadIdx.x / c4;
   if (rl >= lanes) return;
   const long long step = (long long)gridDim.x * lanes;
-  const float invM = 1.f / (float)M;
+  // frozen: the layer normalised with FIXED statistics (eval-mode BatchNorm inside a training module): mean / invstd do not depend on
+  // x, so the two mean-subtraction terms vanish and dx = gamma * invstd * dy
+  const float invM = frozen ? 0.f : 1.f / (float)M;
   for (int cq = threadIdx.x % (c4 < 256 ? c4 : 256); cq < c4; cq += 256) {
     const int c = cq * 4;
     float gi[4], is[4], mu[4], sd[4], sx[4], fb[4];
@@ -577,7 +579,10 @@ extern "C" int bevf_bn_backward_f32(float* dy, const float* y, const float* x, c
   BEVF_REQUIRE(!dx || (x && mean && invstd && dgamma), "bn_backward: dx needs x, mean, invstd, dgamma");
   BEVF_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && cs >= C && cs % 4 == 0, "bn_backward: bad shape");
   // y == NULL: mask recomputed from x (no residual in the forward); relu == 2: additionally dy is left untouched (nobody reads the
-  // masked gradient of a layer without a skip connection) and the second pass masks again: one write of dy less
+  // masked gradient of a layer without a skip connection) and the second pass masks again: one write of dy less.
+  // relu | 4: frozen statistics (mean / invstd are constants, e.g. the running buffers of an eval-mode layer): dx = gamma invstd dy
+  const int frozen = (relu & 4) ? 1 : 0;
+  relu &= 3;
   BEVF_REQUIRE(relu != 2 || (!y && x && mean && invstd), "bn_backward: relu = 2 recomputes the mask from x (y must be NULL)");
   const int relu_mode = relu ? (y ? 1 : (relu == 2 ? 3 : 2)) : 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -589,7 +594,7 @@ extern "C" int bevf_bn_backward_f32(float* dy, const float* y, const float* x, c
   hipLaunchKernelGGL(sums_finalize, dim3(C), dim3(256), 0, st, work, dbeta, dgamma, C, G);
   if (dx)
     hipLaunchKernelGGL(bn_bwd_apply, dim3(row_grid(M, C)), dim3(256), 0, st, dy, x, mean, invstd, gamma,
-                       dbeta, dgamma, dx, (long long)M, C, cs, beta, relu_mode == 3 ? 1 : 0);
+                       dbeta, dgamma, dx, (long long)M, C, cs, beta, relu_mode == 3 ? 1 : 0, frozen);
   return bevf_check_launch("bevf_bn_backward_f32");
 }
 

@@ -122,7 +122,7 @@ class ResNetCameraEncoder(nn.Module):
         return feat, (B, n, hc, wc)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if self.training and _training().any_bn_training(self):
+        if self.training and _training().wants_train_path(self):
             # a freshly built encoder is in train mode (ref src/encoders.py:805, 829): batch statistics + a gradient path
             E.require_cuda(x)
             return _training().camera_encoder_train_forward(self, x)
@@ -341,7 +341,7 @@ class VFELayer(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         E.require_cuda(x)
         B, Nv, P, Cc = x.shape                    # a 3-D input raises ValueError exactly like the reference
-        if self.training and _training().any_bn_training(self):
+        if self.training and _training().wants_train_path(self):
             return _training().vfe_train_forward(self, x)          # batch statistics + gradients for linear / bn
         with torch.no_grad():
             if self._engine is None:

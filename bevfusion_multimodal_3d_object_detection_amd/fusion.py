@@ -103,7 +103,7 @@ class FlexibleBEVFusion(nn.Module):
         E.require_cuda(camera_features, lidar_features, radar_features)
         if self.training:
             from . import training
-            if training.any_bn_training(self):          # used outside the detector in train mode: batch statistics + gradients
+            if training.wants_train_path(self):         # used outside the detector in train mode: batch statistics + gradients
                 return training.fusion_train_forward(self, camera_features, lidar_features, radar_features)
         with torch.no_grad():
             return self._forward_eval(camera_features, lidar_features, radar_features)

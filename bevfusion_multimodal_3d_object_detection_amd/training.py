@@ -276,7 +276,7 @@ def conv_dgrad(dy, weight_oihw, N, H, W, cin, cout, k, stride, pad, add=None, bn
 
 
 class _BNState:
-    __slots__ = ("mean", "invstd", "xraw", "y", "M", "C", "has_res")
+    __slots__ = ("mean", "invstd", "xraw", "y", "M", "C", "has_res", "frozen")
 
 
 # Test instrumentation (tests/test_gpu_training.py): when a list, every train-mode forward site that applies a ReLU appends its
@@ -305,10 +305,33 @@ def bn_pivot_of(bn) -> Optional[torch.Tensor]:
     return rm.detach() if (rm is not None and rm.dtype == torch.float32 and rm.is_cuda) else None
 
 
+def bn_is_frozen(bn) -> bool:
+    """An eval-mode BatchNorm with running statistics inside a module that is being trained normalises with its buffers (torch's rule)."""
+    return (not bn.training) and bn.track_running_stats and bn.running_mean is not None
+
+
 def bn_train_forward(xraw, bn: nn.BatchNorm2d, M: int, Cc: int, res=None, relu=True, apply=True, partials=None):
     """Batch statistics (+ running-buffer update) and, unless apply=False, the normalised activation.
     partials = (part, G, pivot) from a conv epilogue: the statistics are merged from them, xraw is not re-read."""
     dev = xraw.device
+    if bn_is_frozen(bn):
+        # eval-mode BatchNorm inside a module that trains (mixed mode): the running buffers are the statistics, nothing is updated, and
+        # the backward treats them as constants (bevf_bn_backward_f32, relu | 4).  Channel-sized torch arithmetic only.
+        mean = bn.running_mean.detach().float().contiguous()
+        invstd = torch.rsqrt(bn.running_var.detach().float() + bn.eps).contiguous()
+        y = None
+        if apply:
+            y = _new(M * Cc, dev)
+            g = bn.weight.data_ptr() if bn.weight is not None else None
+            b = bn.bias.data_ptr() if bn.bias is not None else None
+            _ck(_lib().bevf_bn_apply_f32(xraw.data_ptr(), mean.data_ptr(), invstd.data_ptr(), g, b,
+                                         res.data_ptr() if res is not None else None, y.data_ptr(), M, Cc, Cc, int(relu), _st()),
+                "bevf_bn_apply_f32")
+            if relu:
+                _trace_relu(y, M, Cc)
+        s = _BNState()
+        s.mean, s.invstd, s.xraw, s.y, s.M, s.C, s.has_res, s.frozen = mean, invstd, xraw, y, M, Cc, res is not None, True
+        return y, s
     mean, var, invstd = _new(Cc, dev), _new(Cc, dev), _new(Cc, dev)
     if partials is not None:
         part, G, pivot = partials
@@ -344,7 +367,7 @@ def bn_train_forward(xraw, bn: nn.BatchNorm2d, M: int, Cc: int, res=None, relu=T
     if relu:
         _trace_relu(y, M, Cc)
     s = _BNState()
-    s.mean, s.invstd, s.xraw, s.y, s.M, s.C, s.has_res = mean, invstd, xraw, y, M, Cc, res is not None
+    s.mean, s.invstd, s.xraw, s.y, s.M, s.C, s.has_res, s.frozen = mean, invstd, xraw, y, M, Cc, res is not None, False
     return y, s
 
 
@@ -362,7 +385,7 @@ def bn_train_backward(dy, s: _BNState, bn, relu=True, need_dx=True):
     _ck(_lib().bevf_bn_backward_f32(dy.data_ptr(), ymask, s.xraw.data_ptr(), s.mean.data_ptr(),
                                     s.invstd.data_ptr(), g, b, work.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                     dx.data_ptr() if dx is not None else None, s.M, s.C, s.C,
-                                    (1 if s.has_res else 2) if relu else 0, _st()),
+                                    ((1 if s.has_res else 2) if relu else 0) | (4 if s.frozen else 0), _st()),
         "bevf_bn_backward_f32")
     return dx, dgamma[:s.C], dbeta[:s.C]
 
@@ -524,7 +547,7 @@ class ConvBNLayer:
             if self.relu:
                 _trace_relu(y, self.M, self.cout)
             return y, Ho, Wo
-        pivot, partials = bn_pivot_of(self.bn), None
+        pivot, partials = (None if bn_is_frozen(self.bn) else bn_pivot_of(self.bn)), None
         if pivot is not None:
             xraw, Ho, Wo, partials = conv_raw(x, w_ohwi, bias, N, H, W, self.cin, self.cout, self.k, self.stride, self.pad, bn_pivot=pivot)
         else:
@@ -574,7 +597,7 @@ class ConvBNLayer:
                     beta=self.bn.bias.detach() if self.bn.bias is not None else None)
 
     def can_take_fused_dy(self) -> bool:
-        return self.bn is not None and self.relu and self.cout % 4 == 0
+        return self.bn is not None and self.relu and self.cout % 4 == 0 and not bn_is_frozen(self.bn)
 
     def backward(self, dy, sink: GradSink, need_dx=True, add=None, fuse_next=None, pre=None):
         """dy: gradient of the layer output (modified in place).  Returns (dx or None, d_res or None); `add` is summed
@@ -765,7 +788,8 @@ class DetectorTape:
         H2, W2 = (H1 - 1) // 2 + 1, (W1 - 1) // 2 + 1
         pooled = _new(N * H2 * W2 * 64, dev)
         self.pool_idx = torch.empty(N * H2 * W2 * 64, dtype=torch.uint8, device=dev)
-        if FUSE_POOL_BN_BACKWARD:
+        self.stem_fused = FUSE_POOL_BN_BACKWARD and not bn_is_frozen(enc.bn1)
+        if self.stem_fused:
             # statistics only; BatchNorm + ReLU are evaluated inside the max-pool: the normalised stem map (1.1 GB) is never written --
             # nothing downstream reads it (the backward recomputes the ReLU mask from the raw conv output)
             _, self.stem_bn = bn_train_forward(raw, enc.bn1, N * H1 * W1, 64, relu=True, apply=False)
@@ -818,7 +842,7 @@ class DetectorTape:
             if i % 2 == 1:
                 sink.ready()                                   # one ResNet stage done: its gradients can travel
         N, H1, W1 = self.pool_geom
-        if FUSE_POOL_BN_BACKWARD:
+        if self.stem_fused:
             # max-pool backward + BatchNorm/ReLU backward in one pair of passes: the dense dY of the stem map (1.1 GB at 48 images of
             # 448x800) is gathered from the pooled gradient on the fly, never written (bit-identical to the two-kernel chain below)
             s = self.stem_bn
@@ -860,9 +884,10 @@ class DetectorTape:
             self.pn_layers.append(lyr)
         lyr = ConvBNLayer(enc.conv5, _bn_or_none(enc.bn5), True)
         self.pn_layers.append(lyr)
-        if lyr.bn is not None:                                       # last layer: BN + ReLU + max over points, fused
+        self.pn_fused_max = lyr.bn is not None and not bn_is_frozen(lyr.bn)
+        if self.pn_fused_max:                                        # last layer: BN + ReLU + max over points, fused
             g, self.pn_idx = lyr.forward_groupmax(a, B, Np)
-        else:                                                        # use_bn=False: the activation is written, then max + argmax
+        else:                                                        # use_bn=False / frozen statistics: the activation is written, then max + argmax
             a, _, _ = lyr.forward(a, M, 1, 1)
             g, self.pn_idx = group_max_with_index(a, B, Np, lyr.cout)
         self.pn_g = g
@@ -871,7 +896,7 @@ class DetectorTape:
     def _lidar_backward(self, dg, sink):
         B, Np, Cc = self.pn_geom
         last = self.pn_layers[-1]
-        if last.bn is not None:
+        if self.pn_fused_max:
             d = last.backward_from_groupmax(dg.contiguous(), self.pn_g, self.pn_idx, B, Np, sink)
         else:
             d = group_max_scatter(dg.contiguous(), self.pn_idx, B, Np, last.cout)
@@ -1232,24 +1257,13 @@ def any_bn_training(module: nn.Module) -> bool:
 
 
 def wants_train_path(module: nn.Module) -> bool:
-    """A module in train mode takes the tape when BatchNorm runs on batch statistics somewhere in it -- or when it has no BatchNorm at
-    all (use_bn=False encoders, ref src/encoders.py:258-269, 520-529) and autograd is recording: the eval engines keep no gradient path."""
-    has_bn = any(isinstance(m, nn.modules.batchnorm._BatchNorm) for m in module.modules())
-    return any_bn_training(module) if has_bn else torch.is_grad_enabled()
-
-
-def _require_all_bn_training(model: nn.Module) -> None:
-    for name, mod in model.named_modules():
-        if isinstance(mod, nn.modules.batchnorm._BatchNorm) and not mod.training:
-            # e.g. _freeze_bn() called AFTER model.train(); the reference's own order (freeze in the constructor, then
-            # model.train() in train_one_epoch, ref src/encoders.py:122-131 + src/train_detect.py:394) leaves every
-            # BatchNorm in train mode with frozen affine parameters, which is what the tape implements
-            raise L.BevfError(f"training: BatchNorm '{name}' is in eval mode inside a module in train mode; the training "
-                              "tape normalises with batch statistics throughout (mixed-mode BatchNorm is not built)")
+    """A module in train mode takes the tape when BatchNorm runs on batch statistics somewhere in it (then even under no_grad: the running
+    buffers move, as in torch) or when autograd is recording -- use_bn=False encoders (ref src/encoders.py:258-269, 520-529) and modules
+    whose BatchNorm layers were all put in eval mode still train their weights; the eval engines keep no gradient path."""
+    return any_bn_training(module) or torch.is_grad_enabled()
 
 
 def detector_train_forward(model, imgs, pts, radars) -> Dict[str, torch.Tensor]:
-    _require_all_bn_training(model)
     params = [p for p in model.parameters() if p.requires_grad]
     outs = _DetectorTrainFn.apply(model, imgs, pts, radars, *params)
     return dict(zip(E.HEAD_BRANCHES, outs))
@@ -1301,7 +1315,6 @@ def _nhwc(x: torch.Tensor) -> torch.Tensor:
 def camera_encoder_train_forward(enc, x: torch.Tensor) -> torch.Tensor:
     """ResNetCameraEncoder.forward under train-mode BatchNorm (ref src/encoders.py:133-172): batch statistics, running buffers
     updated, gradients for every trainable parameter."""
-    _require_all_bn_training(enc)
     _no_input_grad(x, "the camera images")
     five_d = x.dim() == 5
     geom = {}
@@ -1324,7 +1337,6 @@ def camera_encoder_train_forward(enc, x: torch.Tensor) -> torch.Tensor:
 
 def pointnet_train_forward(enc, x: torch.Tensor) -> torch.Tensor:
     """PointNetLiDAREncoder.forward under train-mode BatchNorm (ref src/encoders.py:271-306) -> (B, feat_dim)."""
-    _require_all_bn_training(enc)
     _no_input_grad(x, "the LiDAR points")
     if getattr(enc, "return_point_features", False):
         raise L.BevfError("training: PointNetLiDAREncoder(return_point_features=True) has no train-mode path on the device "
@@ -1347,7 +1359,6 @@ def pointnet_train_forward(enc, x: torch.Tensor) -> torch.Tensor:
 def vfe_train_forward(layer, x: torch.Tensor) -> torch.Tensor:
     """VFELayer.forward under train-mode BatchNorm (ref src/encoders.py:431-455): Linear -> BatchNorm1d over all B*Nv*P rows (padding
     rows included, as the reference) -> ReLU -> max over the P points of a voxel -> (B, Nv, out_channels)."""
-    _require_all_bn_training(layer)
     _no_input_grad(x, "the voxel points")
     B, Nv, P, Cc = x.shape                                        # a 3-D input raises ValueError exactly like the reference
     if Cc > 16:
@@ -1373,7 +1384,6 @@ def vfe_train_forward(layer, x: torch.Tensor) -> torch.Tensor:
 def radar_train_forward(enc, radar_list) -> torch.Tensor:
     """MultiRadarEncoder.forward (ref src/encoders.py:619-661), or one RadarEncoder (ref :527-557, `radar_list` a single tensor),
     under train-mode BatchNorm -> (B, feat_dim)."""
-    _require_all_bn_training(enc)
     single = isinstance(radar_list, torch.Tensor)
     sweeps = [radar_list] if single else list(radar_list)
     for r in sweeps:
@@ -1398,7 +1408,6 @@ def radar_train_forward(enc, radar_list) -> torch.Tensor:
 def fusion_train_forward(fus, camera_features=None, lidar_features=None, radar_features=None) -> torch.Tensor:
     """FlexibleBEVFusion.forward under train-mode BatchNorm (ref src/fusion.py:209-297) -> (B, bev_channels, bev_h, bev_w), with
     gradients for the parameters AND for the three feature inputs."""
-    _require_all_bn_training(fus)
     cam = camera_features if fus.use_camera else None
     lid = lidar_features if fus.use_lidar else None
     rad = radar_features if fus.use_radar else None

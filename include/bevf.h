@@ -425,7 +425,9 @@ int bevf_bn_apply_f32(const float* x, const float* mean, const float* invstd, co
                       const float* res, float* y, int M, int C, int cs, int relu, void* stream);
 /* relu with y == NULL: the mask is recomputed from x exactly as bn_apply computed it (gamma, beta as in the forward;
  * only valid when the forward had no residual input) -- saves reading the forward output.  relu == 2: the same, and
- * dy is left untouched (relu == 1 writes the masked gradient back in place): both passes mask on the fly.         */
+ * dy is left untouched (relu == 1 writes the masked gradient back in place): both passes mask on the fly.
+ * relu | 4: the layer normalised with FIXED statistics (an eval-mode BatchNorm inside a module that trains, mean / invstd =
+ * its running buffers): dgamma / dbeta as always, dx = gamma * invstd * dy (the two mean terms vanish).               */
 int bevf_bn_backward_f32(float* dy, const float* y, const float* x, const float* mean, const float* invstd,
                          const float* gamma, const float* beta, float* work, float* dgamma, float* dbeta, float* dx,
                          int M, int C, int cs, int relu, void* stream);

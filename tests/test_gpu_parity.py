@@ -303,15 +303,10 @@ def test_lidar_resize_extension_128(gpu):
 
 def test_modules_without_a_train_mode_path_refuse_it(gpu):
     """Train-mode BatchNorm runs through training.DetectorTape for the detector and its module kinds
-    (tests/test_gpu_standalone_train.py); mixed-mode BatchNorm is not built and refuses loudly, and so does a VFELayer wider than
-    the small-K point kernel."""
+    (tests/test_gpu_standalone_train.py, mixed-mode BatchNorm included); a VFELayer wider than the small-K point kernel refuses loudly."""
     v = encoders.VFELayer(32, 32).cuda().train()
     with pytest.raises(RuntimeError, match="<= 16 channels"):
         v(torch.zeros(1, 3, 5, 32, device=gpu))
-    m = encoders.ResNetCameraEncoder(backbone="resnet18", pretrained=False).cuda().train()
-    m.layer2[0].bn1.eval()
-    with pytest.raises(RuntimeError, match="mixed-mode BatchNorm"):
-        m(torch.zeros(1, 3, 32, 32, device=gpu))
 
 
 def test_no_modality_raises(gpu):

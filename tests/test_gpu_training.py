@@ -497,10 +497,21 @@ def test_freeze_bn_under_model_train(gpu):
     assert model.camera_encoder.bn1.weight.grad is None and model.camera_encoder.layer3[1].bn2.bias.grad is None
     assert model.fusion.bev_fusion[1].weight.grad is not None                 # BatchNorms outside the camera encoder learn
     assert not torch.equal(before, model.camera_encoder.layer2[0].bn1.running_mean)
-    # freezing AFTER model.train() leaves eval-mode BatchNorms inside a training detector: refused, not silently wrong
+    # freezing AFTER model.train() leaves eval-mode BatchNorms inside a training detector (mixed mode): those layers normalise with their
+    # running buffers, leave them alone and are constants in the backward; everything else trains as before
     model.camera_encoder._freeze_bn()
-    with pytest.raises(Exception, match="eval mode inside a module in train mode"):
-        model(imgs.cuda(), pts.cuda(), None)
+    for m_ in ora.camera_encoder.modules():
+        if isinstance(m_, torch.nn.BatchNorm2d):
+            m_.eval()
+    assert not model.camera_encoder.bn1.training and model.fusion.bev_fusion[1].training
+    model.zero_grad(set_to_none=True)
+    ora.zero_grad(set_to_none=True)
+    before = {n: b.clone() for n, b in model.camera_encoder.named_buffers()}
+    fus_before = model.fusion.bev_fusion[1].running_mean.clone()
+    _grad_check_against_oracle(model, ora, imgs, pts, None, boxes, labels, gpu)
+    for n, b in model.camera_encoder.named_buffers():
+        assert torch.equal(b, before[n]), n
+    assert not torch.equal(fus_before, model.fusion.bev_fusion[1].running_mean)
 
 
 def test_bn_momentum_none_is_a_cumulative_average(gpu):

@@ -79,7 +79,7 @@ def test_oracle_dense_scatter_is_the_references_index_assignment():
 
 def test_train_mode_dispatch_of_the_modules_is_host_logic_that_fails_loudly_without_a_gpu():
     """forward() of an encoder / fusion / head picks the train-mode tape by the BatchNorm flags alone; with CPU tensors both
-    routes refuse (no CPU fallback), and mixed-mode BatchNorm is refused before any kernel is looked up."""
+    routes refuse (no CPU fallback); an eval-mode BatchNorm inside a training module is "frozen" (running statistics, constants in the backward)."""
     from bevfusion_multimodal_3d_object_detection_amd import encoders, centernet_target
     enc = encoders.PointNetLiDAREncoder(input_channels=4, feat_dim=1024)             # a fresh module is in train mode
     assert enc.training and training.any_bn_training(enc)
@@ -91,10 +91,12 @@ def test_train_mode_dispatch_of_the_modules_is_host_logic_that_fails_loudly_with
         enc(torch.zeros(1, 8, 4))
     enc.train()
     enc.bn3.eval()
-    with pytest.raises(L.BevfError, match="mixed-mode BatchNorm"):
-        training._require_all_bn_training(enc)
+    assert training.bn_is_frozen(enc.bn3) and not training.bn_is_frozen(enc.bn2) and training.wants_train_path(enc)
     cam = encoders.ResNetCameraEncoder(backbone="resnet18", pretrained=False, freeze_bn=True)
-    assert cam.training and not training.any_bn_training(cam)                        # frozen BatchNorm: the eval engine's numerics
+    assert cam.training and not training.any_bn_training(cam)                        # frozen BatchNorm everywhere: running statistics
+    assert training.wants_train_path(cam)                                            # ... but the weights still train: the tape
+    with torch.no_grad():
+        assert not training.wants_train_path(cam)                                    # nothing to record, nothing to update: eval engine
     with pytest.raises(L.BevfError, match="no gradient path"):
         training._no_input_grad(torch.zeros(2, requires_grad=True), "the camera images")
     if not torch.cuda.is_available():
