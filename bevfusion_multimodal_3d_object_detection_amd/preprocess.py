@@ -112,7 +112,7 @@ def filter_pad_lidar(points: torch.Tensor, max_points: int = 35000,
     N, Cc = pts.shape
     out = torch.empty(max_points, Cc, device=pts.device)
     count = torch.zeros(1, dtype=torch.int32, device=pts.device)
-    work = torch.empty(max(N, 1) * Cc + 64, device=pts.device)
+    work = torch.empty(max(N, 1) * Cc + (N + 1023) // 1024 + 64, device=pts.device)
     r = (C.c_float * 6)(*pc_range)
     ch = None
     if choice is not None:

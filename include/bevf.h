@@ -518,7 +518,8 @@ int bevf_resize_normalize_u8(const unsigned char* x, float* out, int n, int H, i
 /* One LiDAR sweep [N][C]: keep points strictly inside pc_range6 = (x0,y0,z0,x1,y1,z1), in input order; out
  * [max_points][C] = the survivors then zero rows, or survivors[choice[i]] when `choice` (max_points int64 indices,
  * the reference's np.random.choice) is given and at least max_points survive.  count = number of survivors.
- * work: N*C floats.  Replaces ref src/train_detect.py:150-159, 181-189.                                          */
+ * work: N*C + ceil(N / 1024) floats (the compacted rows, then one counter per tile of 1024 points).  Replaces ref
+ * src/train_detect.py:150-159, 181-189.                                                                          */
 int bevf_lidar_filter_pad_f32(const float* points, float* out, int32_t* count, float* work, const int64_t* choice,
                               int N, int C, int max_points, const float* pc_range6, void* stream);
 
