@@ -18,11 +18,11 @@ __device__ __forceinline__ float ord_float(uint32_t o) {
   return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
 }
 
-// descending bitonic sort of n (power of two) 64-bit keys in LDS by 256 threads
+// descending bitonic sort of n (power of two) 64-bit keys in LDS by the whole workgroup
 __device__ void bitonic_desc(unsigned long long* s, int n) {
   for (int k = 2; k <= n; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < n; i += 256) {
+      for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const int ixj = i ^ j;
         if (ixj > i) {
           const unsigned long long a = s[i], b = s[ixj];
@@ -45,19 +45,17 @@ struct DecArgs {
   float thresh, voxel, x_min, y_min;
 };
 
-// stage A: one workgroup per (frame, class)
-__global__ __launch_bounds__(256) void decode_class_topk(const DecArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned long long* sortbuf = reinterpret_cast<unsigned long long*>(smem);       // [Kp]
-  int* hist = reinterpret_cast<int*>(smem + (size_t)a.Kp * 8);                     // [256]
-  int* sh = hist + 256;                                                            // scratch [264]
-  const int bc = blockIdx.x, tid = threadIdx.x;
+// stage A: one workgroup per (frame, class), 1024 threads (round 3: 256 before -- a map of 128^2 .. 256^2 scores is walked five times by ONE
+// workgroup and only B*C of them exist, so the walks are latency-bound and the wider workgroup is what parallelism there is)
+constexpr int NTA = 1024;
+// keep mask (ref _nms) -> order-preserving score bits, over the whole chip: a value survives iff it equals the 3x3 max around it, else 0
+__global__ __launch_bounds__(256) void decode_keys(const DecArgs a) {
   const int n = a.H * a.W;
-  const float* hp = a.heat + (size_t)bc * n;
-  uint32_t* keys = a.keys + (size_t)bc * n;
-
-  // keep mask (ref _nms): value survives iff it equals the 3x3 max around it, else 0
-  for (int i = tid; i < n; i += 256) {
+  const long long total = (long long)a.B * a.C * n;
+  for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long bc = e / n;
+    const int i = (int)(e - bc * n);
+    const float* hp = a.heat + (size_t)bc * n;
     const int y = i / a.W, x = i - y * a.W;
     const float v = hp[i];
     float m = v;
@@ -69,19 +67,27 @@ __global__ __launch_bounds__(256) void decode_class_topk(const DecArgs a) {
         if ((unsigned)xx < (unsigned)a.W) m = fmaxf(m, hp[yy * a.W + xx]);
       }
     }
-    keys[i] = ord_bits(m == v ? v : 0.f);
+    a.keys[e] = ord_bits(m == v ? v : 0.f);
   }
-  __syncthreads();
+}
+__global__ __launch_bounds__(NTA) void decode_class_topk(const DecArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* sortbuf = reinterpret_cast<unsigned long long*>(smem);       // [Kp]
+  int* hist = reinterpret_cast<int*>(smem + (size_t)a.Kp * 8);                     // [256]
+  int* sh = hist + 256;                                                            // scratch [8 + NTA + 16]
+  const int bc = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = a.H * a.W;
+  const uint32_t* keys = a.keys + (size_t)bc * n;
 
   const int K = a.K < n ? a.K : n;
   // radix select: T = score bits of the K-th largest, need = how many == T still to take
   uint32_t prefix = 0, mask = 0;
   int need = K;
   for (int pass = 3; pass >= 0; --pass) {
-    hist[tid] = 0;
+    if (tid < 256) hist[tid] = 0;
     __syncthreads();
     const int shift = pass * 8;
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += NTA) {
       const uint32_t k = keys[i];
       if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255], 1);
     }
@@ -105,24 +111,26 @@ __global__ __launch_bounds__(256) void decode_class_topk(const DecArgs a) {
   const int n_gt = K - need;
 
   // collect: all > T (any order), then the first `need` (by index) of those == T
-  for (int i = tid; i < a.Kp; i += 256) sortbuf[i] = 0ull;
+  for (int i = tid; i < a.Kp; i += NTA) sortbuf[i] = 0ull;
   if (tid == 0) sh[0] = 0;
   __syncthreads();
-  const int chunk = (n + 255) / 256, lo = tid * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+  const int chunk = (n + NTA - 1) / NTA, lo = tid * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
   int eq = 0;
   for (int i = lo; i < hi; ++i) {
     const uint32_t k = keys[i];
     if (k > T) sortbuf[atomicAdd(&sh[0], 1)] = ((unsigned long long)k << 32) | (uint32_t)(~(uint32_t)i);
     else if (k == T) ++eq;
   }
-  sh[8 + tid] = eq;
-  __syncthreads();
-  if (tid == 0) {           // exclusive scan of 256 per-thread counts (serial: 256 adds, negligible)
-    int run = 0;
-    for (int t = 0; t < 256; ++t) { const int c = sh[8 + t]; sh[8 + t] = run; run += c; }
+  // exclusive scan of the per-thread counts in thread (= index) order: wave scan by shuffles, the 16 wave totals by every thread
+  int incl = eq;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(incl, o);
+    if (lane >= o) incl += up;
   }
+  if (lane == 63) sh[8 + wave] = incl;
   __syncthreads();
-  int rank = sh[8 + tid];
+  int rank = incl - eq;
+  for (int w = 0; w < wave; ++w) rank += sh[8 + w];
   for (int i = lo; i < hi && rank < need; ++i) {
     if (keys[i] == T) {
       sortbuf[n_gt + rank] = ((unsigned long long)T << 32) | (uint32_t)(~(uint32_t)i);
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(256) void decode_class_topk(const DecArgs a) {
   }
   __syncthreads();
   bitonic_desc(sortbuf, a.Kp);
-  for (int i = tid; i < a.K; i += 256) a.cls_top[(size_t)bc * a.K + i] = i < K ? sortbuf[i] : 0ull;
+  for (int i = tid; i < a.K; i += NTA) a.cls_top[(size_t)bc * a.K + i] = i < K ? sortbuf[i] : 0ull;
 }
 
 // stage B: one workgroup per frame: top-K of the C*K pool, gather, boxes
@@ -215,8 +223,12 @@ extern "C" int bevf_centernet_decode_f32(const bevf_decode_desc* d, void* stream
   a.cls_top = reinterpret_cast<unsigned long long*>(w);
   a.keys = reinterpret_cast<uint32_t*>(w + (size_t)d->B * d->C * d->K * sizeof(unsigned long long));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const size_t ldsA = (size_t)a.Kp * 8 + (256 + 264) * sizeof(int);
-  hipLaunchKernelGGL(decode_class_topk, dim3(d->B * d->C), dim3(256), ldsA, st, a);
+  const size_t ldsA = (size_t)a.Kp * 8 + (256 + 8 + 16) * sizeof(int);
+  {
+    const long long total = (long long)d->B * d->C * d->H * d->W, g = (total + 255) / 256;
+    hipLaunchKernelGGL(decode_keys, dim3((unsigned)(g < 8192 ? g : 8192)), dim3(256), 0, st, a);
+  }
+  hipLaunchKernelGGL(decode_class_topk, dim3(d->B * d->C), dim3(NTA), ldsA, st, a);
   hipLaunchKernelGGL(decode_frame, dim3(d->B), dim3(256), (size_t)a.poolp * 8, st, a);
   return bevf_check_launch("bevf_centernet_decode_f32");
 }
