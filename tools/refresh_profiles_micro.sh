@@ -7,6 +7,12 @@ echo "conv3x3 bench done"
 { for lt in layer1:1 layer3:0 fusion1_c3:0; do echo "== ${lt%:*} (tile ${lt#*:})"; timeout -k 10 120 python tools/conv3x3_stamps.py ${lt%:*} ${lt#*:}; done; } > gpurun_out/r03_conv3x3_stamps.txt 2>&1
 echo "stamps done"
 { timeout -k 10 200 python tools/frontend_bench.py 3
+  # the A/B library = this tree's objects + the round-2 voxeliser (build/old/voxelize_r2.o: hipcc -c of `git show f202bdd:.../csrc/voxelize.hip`);
+  # relinked here so that it always exports the current symbol set
+  if [ -f build/old/voxelize_r2.o ]; then
+    hipcc --offload-arch=gfx950 -shared -fPIC -o build/old/libbevf_oldvox.so \
+      $(ls bevfusion_multimodal_3d_object_detection_amd/csrc/*.o | grep -v "/voxelize.o") build/old/voxelize_r2.o
+  fi
   if [ -f build/old/libbevf_oldvox.so ]; then
     echo "== round-2 voxeliser (BEVF_AB_LIB=build/old/libbevf_oldvox.so)"
     BEVF_AB_LIB=build/old/libbevf_oldvox.so timeout -k 10 200 python tools/frontend_bench.py 3
