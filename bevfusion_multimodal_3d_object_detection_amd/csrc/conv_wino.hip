@@ -30,6 +30,13 @@ namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// a - b on two floats at once (same rounding as two v_sub_f32)
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
 #define MFMA(acc_, a_, b_) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc_) : "v"(a_), "v"(b_))
 #define MFMA0(acc_, a_, b_) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=a"(acc_) : "v"(a_), "v"(b_))
 
@@ -403,22 +410,32 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
               fb = (p.bnb_beta ? p.bnb_beta[cch] : 0.f) - mu * fa;
             }
           }
-          f32x4 sr[2][4];                                            // A^T M over the frequency rows, all four tiles r at once
+          // A^T M over the frequency rows, all four tiles r at once -- as two-float halves with the subtractions as explicit packed
+          // instructions: left to hipcc every vector subtraction here became scalar v_sub_f32 (192 per epilogue beside fp32 MFMAs' shared pipe)
+          f32x2 sr[2][4][2];
 #pragma unroll
-          for (int nu = 0; nu < 4; ++nu) {
-            const f32x4 m0 = acc[0 + nu][nb], m1 = acc[4 + nu][nb], m2 = acc[8 + nu][nb], m3 = acc[12 + nu][nb];
-            sr[0][nu] = m0 + m1 + m2;
-            sr[1][nu] = m1 - m2 - m3;
-          }
+          for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              const f32x2 m0 = {acc[0 + nu][nb][2 * hh], acc[0 + nu][nb][2 * hh + 1]}, m1 = {acc[4 + nu][nb][2 * hh], acc[4 + nu][nb][2 * hh + 1]};
+              const f32x2 m2 = {acc[8 + nu][nb][2 * hh], acc[8 + nu][nb][2 * hh + 1]}, m3 = {acc[12 + nu][nb][2 * hh], acc[12 + nu][nb][2 * hh + 1]};
+              sr[0][nu][hh] = m0 + m1 + m2;
+              sr[1][nu][hh] = pk_sub(pk_sub(m1, m2), m3);
+            }
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            const f32x4 yv[2] = {sr[i][0] + sr[i][1] + sr[i][2], sr[i][1] - sr[i][2] - sr[i][3]};
+            f32x2 yh[2][2];                                          // [j][half]
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              yh[0][hh] = sr[i][0][hh] + sr[i][1][hh] + sr[i][2][hh];
+              yh[1][hh] = pk_sub(pk_sub(sr[i][1][hh], sr[i][2][hh]), sr[i][3][hh]);
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const int q = r * 4 + i * 2 + j;
-                float o = fmaf(yv[j][r], sc[nb], sh[nb]);
+                float o = fmaf(yh[j][r >> 1][r & 1], sc[nb], sh[nb]);
                 if constexpr (RES) o += rv[set][q];
                 if constexpr (RELU) o = fmaxf(o, 0.f);
                 if constexpr (BNB != 0) {                             // the consumer's ReLU mask, then its backward sums
