@@ -430,12 +430,18 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
               yh[0][hh] = sr[i][0][hh] + sr[i][1][hh] + sr[i][2][hh];
               yh[1][hh] = pk_sub(pk_sub(sr[i][1][hh], sr[i][2][hh]), sr[i][3][hh]);
             }
+            const f32x2 sc2 = {sc[nb], sc[nb]}, sh2 = {sh[nb], sh[nb]};
+            f32x2 of[2][2];                                          // folded BatchNorm on pairs (v_pk_fma_f32)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int hh = 0; hh < 2; ++hh) of[j][hh] = __builtin_elementwise_fma(yh[j][hh], sc2, sh2);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const int q = r * 4 + i * 2 + j;
-                float o = fmaf(yh[j][r >> 1][r & 1], sc[nb], sh[nb]);
+                float o = of[j][r >> 1][r & 1];
                 if constexpr (RES) o += rv[set][q];
                 if constexpr (RELU) o = fmaxf(o, 0.f);
                 if constexpr (BNB != 0) {                             // the consumer's ReLU mask, then its backward sums
