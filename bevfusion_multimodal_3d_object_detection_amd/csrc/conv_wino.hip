@@ -169,7 +169,14 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
   const int b_lane = kq * 64 + t * 4;                              // floats within a [4 kq][16 n][2 nb][2 cin] block: lane * 16 bytes, linear
 
   f32x4 acc[16][4];
-  f32x2 v[16], dn[16];
+#ifndef WINO_ONE_CLUSTER
+#define WINO_ONE_CLUSTER 1
+#endif
+  // A fragments: two sets (WINO_ONE_CLUSTER: group g multiplies from set g & 1 while the WHOLE input transform of group g + 1 is written
+  // into the other set in ONE MFMA gap -- a lone VALU instruction between fp32 MFMAs costs ~15 cycles, the ones right behind it ~3
+  // (probe), so 32 packed adds cost ~120 cycles as one cluster and ~250 as the twelve they used to be)
+  f32x2 vv[WINO_ONE_CLUSTER ? 2 : 1][16], dn[16];
+  f32x2 (&v)[16] = vv[0];
   auto load_patch = [&](int buf, int gl, int q) {                  // row q of the 4x4 patch -> dn[4q..4q+3]
     const float* pa = patch + buf * PATCH_FLOATS + a_lane + gl * 8;
 #pragma unroll
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
     for (int f = 0; f < 16; ++f) {
       f32x4 (&bc)[2] = (f & 1) ? b1 : b0;
       f32x4 (&bn)[2] = (f & 1) ? b0 : b1;
-      const f32x2 a = v[f];
+      const f32x2 a = vv[WINO_ONE_CLUSTER ? (gl & 1) : 0][f];
       // 8 MFMAs; after each one a small piece of the other work, pinned in place, so that every non-MFMA instruction
       // issues in the shadow of an executing MFMA (one wave per SIMD: nothing else would fill the gap)
 #pragma unroll
@@ -248,6 +255,21 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const WinoArgs p) {
                         dn[4 * f + 1] = *reinterpret_cast<const f32x2*>(pa + (f * PWP + 1) * PITCH); }
           if (k == 3) { dn[4 * f + 2] = *reinterpret_cast<const f32x2*>(pa + (f * PWP + 2) * PITCH);
                         dn[4 * f + 3] = *reinterpret_cast<const f32x2*>(pa + (f * PWP + 3) * PITCH); }
+        } else if (WINO_ONE_CLUSTER) {
+          if (f == 5 && k == 2) {                                   // patch rows landed (read at f < 4): B^T d B, all of it
+            f32x2 (&vn)[16] = vv[WINO_ONE_CLUSTER ? ((gl + 1) & 1) : 0];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const f32x2 t0 = dn[0 + c] - dn[8 + c], t1 = dn[4 + c] + dn[8 + c];
+              const f32x2 t2 = dn[8 + c] - dn[4 + c], t3 = dn[4 + c] - dn[12 + c];
+              dn[0 + c] = t0; dn[4 + c] = t1; dn[8 + c] = t2; dn[12 + c] = t3;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              vn[4 * r + 0] = dn[4 * r + 0] - dn[4 * r + 2]; vn[4 * r + 1] = dn[4 * r + 1] + dn[4 * r + 2];
+              vn[4 * r + 2] = dn[4 * r + 2] - dn[4 * r + 1]; vn[4 * r + 3] = dn[4 * r + 1] - dn[4 * r + 3];
+            }
+          }
         } else if (f < 8) {                                         // B^T d, column c = f - 4: four f32x2 ops
           const int c = f - 4;
           if (k == 2) { const f32x2 t0 = dn[0 + c] - dn[8 + c], t1 = dn[4 + c] + dn[8 + c];
