@@ -158,11 +158,29 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_f32(const WwArgs p) {
     const int so = s * 4 * TE_BYTES + (which == 0 ? selA : which == 1 ? selB : selY);
     tab[set][which] = __builtin_bit_cast(i32x4, buf_load16(rst, ktab, so));
   };
+#ifndef WGRAD_CLUSTER
+#define WGRAD_CLUSTER 1
+#endif
+  // A lone VALU instruction between two fp32 MFMAs costs ~15 cycles, the ones right behind it ~3 (probe in conv_wino.hip / DESIGN 3.1b):
+  // the twelve address adds of a step are ONE cluster (px_addr, then twelve plain loads in the following gaps), the 24 transform
+  // instructions another -- 2 interruptions per 64 MFMAs instead of 36.
+  int pxa[12];
+  auto px_addr = [&](auto tsetc) {
+    constexpr int ts = decltype(tsetc)::value;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) pxa[i] = v_add(tab[ts][i >> 2][i & 3], q16);
+  };
   auto load_px = [&](auto setc, auto tsetc, auto ic_) {   // pixel i of table set tset: 0..3 row A, 4..7 row B, 8..11 dY
     constexpr int set = decltype(setc)::value, ts = decltype(tsetc)::value, i = decltype(ic_)::value;
-    if constexpr (i < 4) rx[set][0][i] = buf_load16(rsx, v_add(tab[ts][0][i], q16), 0);
-    else if constexpr (i < 8) rx[set][1][i - 4] = buf_load16(rsx, v_add(tab[ts][1][i - 4], q16), 0);
-    else ry[set][(i - 8) >> 1][(i - 8) & 1] = buf_load16(rsy, v_add(tab[ts][2][i - 8], q16), 0);
+    if constexpr (WGRAD_CLUSTER) {
+      if constexpr (i < 4) rx[set][0][i] = buf_load16(rsx, pxa[i], 0);
+      else if constexpr (i < 8) rx[set][1][i - 4] = buf_load16(rsx, pxa[i], 0);
+      else ry[set][(i - 8) >> 1][(i - 8) & 1] = buf_load16(rsy, pxa[i], 0);
+    } else {
+      if constexpr (i < 4) rx[set][0][i] = buf_load16(rsx, v_add(tab[ts][0][i], q16), 0);
+      else if constexpr (i < 8) rx[set][1][i - 4] = buf_load16(rsx, v_add(tab[ts][1][i - 4], q16), 0);
+      else ry[set][(i - 8) >> 1][(i - 8) & 1] = buf_load16(rsy, v_add(tab[ts][2][i - 8], q16), 0);
+    }
   };
   auto xform = [&](auto setc, auto jc) {              // transform step j of raw set -> operand set, one packed instruction each
     constexpr int set = decltype(setc)::value, j = decltype(jc)::value;
@@ -191,6 +209,7 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_f32(const WwArgs p) {
     xform(setc, ic<18>{}); xform(setc, ic<19>{}); xform(setc, ic<20>{}); xform(setc, ic<21>{}); xform(setc, ic<22>{}); xform(setc, ic<23>{});
   };
   auto load_px_all = [&](auto setc, auto ts) {
+    if constexpr (WGRAD_CLUSTER) px_addr(ts);
     load_px(setc, ts, ic<0>{}); load_px(setc, ts, ic<1>{}); load_px(setc, ts, ic<2>{}); load_px(setc, ts, ic<3>{});
     load_px(setc, ts, ic<4>{}); load_px(setc, ts, ic<5>{}); load_px(setc, ts, ic<6>{}); load_px(setc, ts, ic<7>{});
     load_px(setc, ts, ic<8>{}); load_px(setc, ts, ic<9>{}); load_px(setc, ts, ic<10>{}); load_px(setc, ts, ic<11>{});
@@ -218,6 +237,7 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_f32(const WwArgs p) {
           if (m == 0) load_tab(CS, s + 3, ic<0>{});
           if (m == 1) load_tab(CS, s + 3, ic<1>{});
           if (m == 2) load_tab(CS, s + 3, ic<2>{});
+          if (m == 3 && WGRAD_CLUSTER) px_addr(NS);
           if (m == 3) load_px(CS, NS, ic<0>{});
           if (m == 4) load_px(CS, NS, ic<1>{});
           if (m == 5) load_px(CS, NS, ic<2>{});
@@ -230,30 +250,34 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_f32(const WwArgs p) {
           if (m == 12) load_px(CS, NS, ic<9>{});
           if (m == 13) load_px(CS, NS, ic<10>{});
           if (m == 14) load_px(CS, NS, ic<11>{});
-          if (m == 38) xform(NS, ic<0>{});
-          if (m == 39) xform(NS, ic<1>{});
-          if (m == 40) xform(NS, ic<2>{});
-          if (m == 41) xform(NS, ic<3>{});
-          if (m == 42) xform(NS, ic<4>{});
-          if (m == 43) xform(NS, ic<5>{});
-          if (m == 44) xform(NS, ic<6>{});
-          if (m == 45) xform(NS, ic<7>{});
-          if (m == 46) xform(NS, ic<8>{});
-          if (m == 47) xform(NS, ic<9>{});
-          if (m == 48) xform(NS, ic<10>{});
-          if (m == 49) xform(NS, ic<11>{});
-          if (m == 50) xform(NS, ic<12>{});
-          if (m == 51) xform(NS, ic<13>{});
-          if (m == 52) xform(NS, ic<14>{});
-          if (m == 53) xform(NS, ic<15>{});
-          if (m == 54) xform(NS, ic<16>{});
-          if (m == 55) xform(NS, ic<17>{});
-          if (m == 56) xform(NS, ic<18>{});
-          if (m == 57) xform(NS, ic<19>{});
-          if (m == 58) xform(NS, ic<20>{});
-          if (m == 59) xform(NS, ic<21>{});
-          if (m == 60) xform(NS, ic<22>{});
-          if (m == 61) xform(NS, ic<23>{});
+          if (WGRAD_CLUSTER) {
+            if (m == 38) xform_all(NS);
+          } else {
+            if (m == 38) xform(NS, ic<0>{});
+            if (m == 39) xform(NS, ic<1>{});
+            if (m == 40) xform(NS, ic<2>{});
+            if (m == 41) xform(NS, ic<3>{});
+            if (m == 42) xform(NS, ic<4>{});
+            if (m == 43) xform(NS, ic<5>{});
+            if (m == 44) xform(NS, ic<6>{});
+            if (m == 45) xform(NS, ic<7>{});
+            if (m == 46) xform(NS, ic<8>{});
+            if (m == 47) xform(NS, ic<9>{});
+            if (m == 48) xform(NS, ic<10>{});
+            if (m == 49) xform(NS, ic<11>{});
+            if (m == 50) xform(NS, ic<12>{});
+            if (m == 51) xform(NS, ic<13>{});
+            if (m == 52) xform(NS, ic<14>{});
+            if (m == 53) xform(NS, ic<15>{});
+            if (m == 54) xform(NS, ic<16>{});
+            if (m == 55) xform(NS, ic<17>{});
+            if (m == 56) xform(NS, ic<18>{});
+            if (m == 57) xform(NS, ic<19>{});
+            if (m == 58) xform(NS, ic<20>{});
+            if (m == 59) xform(NS, ic<21>{});
+            if (m == 60) xform(NS, ic<22>{});
+            if (m == 61) xform(NS, ic<23>{});
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
       }

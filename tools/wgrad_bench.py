@@ -10,6 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.nn.functional as F
 
+from bevfusion_multimodal_3d_object_detection_amd import _lib as _L
+if os.environ.get("BEVF_AB_LIB"): _L.LIB_PATH = os.environ["BEVF_AB_LIB"]          # A/B against another build of the library
 from bevfusion_multimodal_3d_object_detection_amd import training as T
 
 dev = torch.device("cuda")
